@@ -1,0 +1,24 @@
+# Top-level build: the product (libmi_denoise.so, gfx950 only) and the checker (oracle/).
+HIPCC   ?= /opt/rocm/bin/hipcc
+ARCH    ?= gfx950
+CSRC    := image_denoising_filter_amd/csrc
+LIB     := image_denoising_filter_amd/libmi_denoise.so
+SRCS    := $(CSRC)/capi.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/pipeline.cpp
+OBJS    := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
+HIPFLAGS := -x hip --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude
+
+all: $(LIB) oracle
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+build/%.o: $(CSRC)/% $(CSRC)/common.hpp include/mi_denoise.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB); $(MAKE) -C oracle clean
+.PHONY: all oracle clean

@@ -1,0 +1,88 @@
+"""ctypes loader for libmi_denoise.so (the C-ABI of include/mi_denoise.h).
+
+The product path has no fallback: if the shared library is missing or does not load,
+import of this module raises.  torch is imported FIRST on purpose: the PyTorch-ROCm wheel
+carries its own libamdhip64.so.7, and a process must not end up with two HIP runtimes
+(device pointers and streams would not be shared).  Loading torch first makes the
+dynamic linker resolve this library's libamdhip64.so.7 dependency to the copy that is
+already mapped, so torch tensors' data_ptr() and torch streams can be handed to the C-ABI.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (see module docstring: must precede the CDLL below)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi_denoise.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()). "
+        "image_denoising_filter_amd has no CPU or PyTorch fallback."
+    )
+
+lib = ctypes.CDLL(LIB_PATH)
+
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+
+class BilateralParams(ctypes.Structure):
+    """mid_bilateral_params (first 16 bytes = the push-constant block of bialteral.comp:13-20)."""
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("spatialSigma", ctypes.c_float), ("colorSigma", ctypes.c_float),
+                ("radius", ctypes.c_int32), ("layout", ctypes.c_int32), ("format", ctypes.c_int32)]
+
+
+class NlmParams(ctypes.Structure):
+    """mid_nlm_params (first 12 bytes = the push-constant block of nonlocal.comp:16-22)."""
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("filteringParameter", ctypes.c_float),
+                ("search_lo", ctypes.c_int32), ("search_hi", ctypes.c_int32),
+                ("patch_lo", ctypes.c_int32), ("patch_hi", ctypes.c_int32),
+                ("format", ctypes.c_int32)]
+
+
+class NormalizeParams(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32)]
+
+
+# every symbol include/mi_denoise.h declares, with its signature
+_P = ctypes.c_void_p
+_SIGNATURES = {
+    "mid_ctx_create": (ctypes.c_int, [ctypes.c_int, c_void_pp]),
+    "mid_ctx_destroy": (None, [_P]),
+    "mid_last_error": (ctypes.c_char_p, []),
+    "mid_version": (ctypes.c_int, []),
+    "mid_device_name": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),
+    "mid_alloc": (ctypes.c_int, [_P, ctypes.c_size_t, c_void_pp]),
+    "mid_free": (ctypes.c_int, [_P, _P]),
+    "mid_alloc_host": (ctypes.c_int, [_P, ctypes.c_size_t, c_void_pp]),
+    "mid_free_host": (ctypes.c_int, [_P, _P]),
+    "mid_memcpy_h2d": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
+    "mid_memcpy_d2h": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
+    "mid_memset": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_size_t, _P]),
+    "mid_stream_sync": (ctypes.c_int, [_P, _P]),
+    "mid_bilateral": (ctypes.c_int, [_P, ctypes.POINTER(BilateralParams), _P, _P, _P]),
+    "mid_bilateral_layers_accum": (ctypes.c_int, [_P, ctypes.POINTER(BilateralParams), _P, _P, _P, _P]),
+    "mid_bilateral_layers": (ctypes.c_int, [_P, ctypes.POINTER(BilateralParams), _P, c_void_pp, ctypes.c_int, _P, _P]),
+    "mid_nlm_accum": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), _P, _P, _P, _P]),
+    "mid_nlm_temporal": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), c_void_pp, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, c_void_pp, _P]),
+    "mid_normalize": (ctypes.c_int, [_P, ctypes.POINTER(NormalizeParams), _P, _P, _P]),
+    "mid_unpack_u8": (ctypes.c_int, [_P, _P, ctypes.c_size_t, ctypes.c_int, _P, _P]),
+    "mid_pack_u8": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
+    "mid_sequence_nlm": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), c_void_pp, ctypes.c_int, ctypes.c_int,
+                                        c_void_pp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
+    "mid_timer_create": (ctypes.c_int, [_P, c_void_pp]),
+    "mid_timer_destroy": (ctypes.c_int, [_P]),
+    "mid_timer_tick": (ctypes.c_int, [_P, _P]),
+    "mid_timer_tock": (ctypes.c_int, [_P, _P]),
+    "mid_timer_ms": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
+}
+
+for _name, (_res, _args) in _SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the .so does not export what the header declares
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED = tuple(_SIGNATURES)

@@ -1,0 +1,261 @@
+"""Host-side mirror of the reference's kernel interface, over the C-ABI.
+
+The reference drives its kernels through ComputeApplication::RunOnGPU (src/main.cpp:1307-1730):
+bind {output / WeightInfo buffer, image(s)}, push {w, h, sigmas | h}, dispatch.  `Context`
+offers the same operators with the same argument meaning; every call goes through
+libmi_denoise.so (ctypes) -- there is no NumPy/PyTorch compute path here, and a missing
+library or GPU is an error, not a fallback.
+
+NumPy arrays are (h, w, 4): float32 = RGBA32F (.exr path), uint8 = RGBA8 (.png path).
+WeightInfo buffers are float32 (h, w, 8): [wc.r, wc.g, wc.b, wc.a, normWeight, pad, pad, pad].
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import BilateralParams, NlmParams, NormalizeParams, c_void_pp, lib
+
+FMT_RGBA32F, FMT_RGBA8 = 0, 1
+LAYOUT_TEXTURE, LAYOUT_LINEAR = 0, 1
+
+# nonlocal.comp:5-6 as shipped, and the 21x21 / 7x7 benchmark configuration (half-open ranges)
+NLM_REFERENCE = dict(search=(-7, 7), patch=(-3, 3))
+NLM_BENCH = dict(search=(-10, 11), patch=(-3, 4))
+
+
+class MidError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib.mid_last_error().decode("utf-8", "replace")
+        super().__init__(f"{where}: error {code}: {msg}")
+
+
+def _check(code, where):
+    if code != 0:
+        raise MidError(code, where)
+
+
+class DeviceBuffer:
+    """A hipMalloc'd buffer owned by Python (the application owns every buffer, like the reference)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = ctypes.c_void_p()
+        _check(lib.mid_alloc(ctx.handle, self.nbytes, ctypes.byref(p)), "mid_alloc")
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            lib.mid_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _fmt_of(a):
+    if a.dtype == np.float32:
+        return FMT_RGBA32F
+    if a.dtype == np.uint8:
+        return FMT_RGBA8
+    raise TypeError(f"image dtype must be float32 or uint8, got {a.dtype}")
+
+
+def _img(a):
+    a = np.ascontiguousarray(a)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError(f"image must be (h, w, 4), got {a.shape}")
+    return a
+
+
+class Context:
+    """One device + its streams (mid_ctx).  Replaces the reference's Vulkan instance/device/queue."""
+
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        _check(lib.mid_ctx_create(int(device), ctypes.byref(h)), "mid_ctx_create")
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            lib.mid_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def name(self):
+        buf = ctypes.create_string_buffer(160)
+        _check(lib.mid_device_name(self.handle, buf, 160), "mid_device_name")
+        return buf.value.decode()
+
+    # ---- memory ---------------------------------------------------------------------------
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, arr, stream=None):
+        arr = np.ascontiguousarray(arr)
+        buf = DeviceBuffer(self, max(arr.nbytes, 16))
+        if arr.nbytes:
+            _check(lib.mid_memcpy_h2d(self.handle, buf.ptr, arr.ctypes.data, arr.nbytes, stream), "mid_memcpy_h2d")
+            self.sync(stream)
+        return buf
+
+    def download(self, buf, shape, dtype, stream=None):
+        out = np.empty(shape, dtype=dtype)
+        ptr = buf.ptr if isinstance(buf, DeviceBuffer) else int(buf)
+        if out.nbytes:
+            _check(lib.mid_memcpy_d2h(self.handle, out.ctypes.data, ptr, out.nbytes, stream), "mid_memcpy_d2h")
+            self.sync(stream)
+        return out
+
+    def zeros(self, nbytes, stream=None):
+        buf = DeviceBuffer(self, nbytes)
+        _check(lib.mid_memset(self.handle, buf.ptr, 0, nbytes, stream), "mid_memset")
+        return buf
+
+    def sync(self, stream=None):
+        _check(lib.mid_stream_sync(self.handle, stream), "mid_stream_sync")
+
+    # ---- raw (device pointer) operators: what bench.py and the pipeline use ------------------
+    def bilateral_dev(self, in_ptr, out_ptr, w, h, radius, sigma_s, sigma_c, layout, fmt, stream=None):
+        p = BilateralParams(w, h, sigma_s, sigma_c, radius, layout, fmt)
+        _check(lib.mid_bilateral(self.handle, ctypes.byref(p), in_ptr, out_ptr, stream), "mid_bilateral")
+
+    def nlm_temporal_dev(self, frame_ptrs, out_ptrs, w, h, hparam, search, patch, k, first, count, fmt, stream=None):
+        p = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], fmt)
+        fr = (ctypes.c_void_p * len(frame_ptrs))(*frame_ptrs)
+        ou = (ctypes.c_void_p * len(out_ptrs))(*out_ptrs)
+        _check(lib.mid_nlm_temporal(self.handle, ctypes.byref(p), fr, len(frame_ptrs), k, first, count, ou, stream),
+               "mid_nlm_temporal")
+
+    # ---- NumPy-level operators (tests, smoke) ----------------------------------------------
+    def bilateral(self, img, radius, sigma_s=2.0, sigma_c=0.2, layout="texture"):
+        """bialteral.comp (layout='texture') / bialteral_linear.comp (layout='linear')."""
+        img = _img(img)
+        h, w = img.shape[:2]
+        lay = {"texture": LAYOUT_TEXTURE, "linear": LAYOUT_LINEAR}[layout]
+        d_in, d_out = self.upload(img), self.alloc(w * h * 16)
+        self.bilateral_dev(d_in.ptr, d_out.ptr, w, h, radius, sigma_s, sigma_c, lay, _fmt_of(img))
+        return self.download(d_out, (h, w, 4), np.float32)
+
+    def bilateral_layers_accum(self, img, layer, W, radius, sigma_s=2.0, sigma_c=0.2):
+        """One dispatch of bialteral_layers.comp: returns W + this layer's sums."""
+        img, layer = _img(img), _img(layer)
+        if layer.dtype != np.uint8:
+            raise TypeError("layers are always RGBA8 (src/main.cpp:1396)")
+        h, w = img.shape[:2]
+        W = np.ascontiguousarray(W, dtype=np.float32)
+        d_in, d_l, d_w = self.upload(img), self.upload(layer), self.upload(W)
+        p = BilateralParams(w, h, sigma_s, sigma_c, radius, LAYOUT_TEXTURE, _fmt_of(img))
+        _check(lib.mid_bilateral_layers_accum(self.handle, ctypes.byref(p), d_in.ptr, d_l.ptr, d_w.ptr, None),
+               "mid_bilateral_layers_accum")
+        return self.download(d_w, (h, w, 8), np.float32)
+
+    def bilateral_layers(self, img, layers, radius, sigma_s=2.0, sigma_c=0.2):
+        """The per-layer loop + normalize, fused (src/main.cpp:1610-1623,1649-1652)."""
+        img = _img(img)
+        h, w = img.shape[:2]
+        d_in, d_out = self.upload(img), self.alloc(w * h * 16)
+        d_layers = [self.upload(_img(l)) for l in layers]
+        tbl = (ctypes.c_void_p * max(len(d_layers), 1))(*[d.ptr for d in d_layers])
+        p = BilateralParams(w, h, sigma_s, sigma_c, radius, LAYOUT_TEXTURE, _fmt_of(img))
+        _check(lib.mid_bilateral_layers(self.handle, ctypes.byref(p), d_in.ptr, tbl, len(d_layers), d_out.ptr, None),
+               "mid_bilateral_layers")
+        return self.download(d_out, (h, w, 4), np.float32)
+
+    def nlm_accum(self, target, neighbour, W, hparam=0.5, search=(-7, 7), patch=(-3, 3)):
+        """One dispatch of nonlocal.comp: returns W + this neighbour frame's sums."""
+        target, neighbour = _img(target), _img(neighbour)
+        h, w = target.shape[:2]
+        W = np.ascontiguousarray(W, dtype=np.float32)
+        d_t, d_n, d_w = self.upload(target), self.upload(neighbour), self.upload(W)
+        p = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], _fmt_of(target))
+        _check(lib.mid_nlm_accum(self.handle, ctypes.byref(p), d_t.ptr, d_n.ptr, d_w.ptr, None), "mid_nlm_accum")
+        return self.download(d_w, (h, w, 8), np.float32)
+
+    def nlm_temporal(self, frames, k=0, first=0, count=None, hparam=0.5, search=(-7, 7), patch=(-3, 3)):
+        """Fused accumulate-over-neighbour-frames + normalize for `count` output frames."""
+        frames = [_img(f) for f in frames]
+        count = len(frames) - first if count is None else count
+        h, w = frames[0].shape[:2]
+        d_fr = [self.upload(f) for f in frames]
+        d_out = [self.alloc(w * h * 16) for _ in range(count)]
+        self.nlm_temporal_dev([d.ptr for d in d_fr], [d.ptr for d in d_out], w, h, hparam, search, patch,
+                              k, first, count, _fmt_of(frames[0]))
+        return [self.download(d, (h, w, 4), np.float32) for d in d_out]
+
+    def normalize(self, W):
+        """normalize.comp."""
+        W = np.ascontiguousarray(W, dtype=np.float32)
+        h, w = W.shape[:2]
+        d_w, d_out = self.upload(W), self.alloc(w * h * 16)
+        p = NormalizeParams(w, h)
+        _check(lib.mid_normalize(self.handle, ctypes.byref(p), d_w.ptr, d_out.ptr, None), "mid_normalize")
+        return self.download(d_out, (h, w, 4), np.float32)
+
+    def unpack_u8(self, u8, flavour=0):
+        u8 = np.ascontiguousarray(u8, dtype=np.uint8)
+        n = u8.size
+        d_in, d_out = self.upload(u8), self.alloc(max(n * 4, 16))
+        _check(lib.mid_unpack_u8(self.handle, d_in.ptr, n, flavour, d_out.ptr, None), "mid_unpack_u8")
+        return self.download(d_out, u8.shape, np.float32)
+
+    def pack_u8(self, f32):
+        f32 = np.ascontiguousarray(f32, dtype=np.float32)
+        n = f32.size
+        d_in, d_out = self.upload(f32), self.alloc(max(n, 16))
+        _check(lib.mid_pack_u8(self.handle, d_in.ptr, n, d_out.ptr, None), "mid_pack_u8")
+        return self.download(d_out, f32.shape, np.uint8)
+
+    def sequence_nlm(self, frames, k=2, overlap=True, hparam=0.5, search=(-7, 7), patch=(-3, 3), pinned=True):
+        """Host frames in, host frames out through the 3-stream pipeline (mid_sequence_nlm).
+        Returns (outputs, (wall_ms, kernel_ms, copy_ms))."""
+        frames = [_img(f) for f in frames]
+        n = len(frames)
+        h, w = frames[0].shape[:2]
+        fmt = _fmt_of(frames[0])
+        in_bytes, out_bytes = frames[0].nbytes, w * h * 16
+        hin, hout = [], []
+        try:
+            for f in frames:
+                p = ctypes.c_void_p()
+                if pinned:
+                    _check(lib.mid_alloc_host(self.handle, in_bytes, ctypes.byref(p)), "mid_alloc_host")
+                    ctypes.memmove(p.value, f.ctypes.data, in_bytes)
+                    hin.append(p.value)
+                else:
+                    hin.append(f.ctypes.data)
+                q = ctypes.c_void_p()
+                _check(lib.mid_alloc_host(self.handle, out_bytes, ctypes.byref(q)), "mid_alloc_host")
+                hout.append(q.value)
+            prm = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], fmt)
+            t = (ctypes.c_float * 3)()
+            _check(lib.mid_sequence_nlm(self.handle, ctypes.byref(prm), (ctypes.c_void_p * n)(*hin), n, k,
+                                        (ctypes.c_void_p * n)(*hout), 1 if overlap else 0, t), "mid_sequence_nlm")
+            outs = []
+            for q in hout:
+                o = np.empty((h, w, 4), np.float32)
+                ctypes.memmove(o.ctypes.data, q, out_bytes)
+                outs.append(o)
+            return outs, tuple(t)
+        finally:
+            if pinned:
+                for p in hin:
+                    lib.mid_free_host(self.handle, p)
+            for q in hout:
+                lib.mid_free_host(self.handle, q)

@@ -1,0 +1,308 @@
+// bilateral.hip -- bilateral filters for gfx950 (replaces shaders/bialteral.comp,
+// bialteral_linear.comp and bialteral_layers.comp).
+//
+// Design.  A workgroup stages its output tile plus a `radius` halo in LDS as float4 texels
+// (coalesced 16 B/lane HBM reads, halo zero-filled per the reference's out-of-image policy).
+// A wave owns 64 adjacent columns x P rows: lane l owns one column and P vertically adjacent
+// outputs, so each LDS texel it reads (one conflict-free ds_read_b128) feeds up to P taps.
+// Per tap: 3 sub, 3 mul/fma (colour distance), 1 fma folding the colour and the spatial
+// exponent, 1 v_exp_f32, 4 fma + 1 add.  The two exp() of the shader become one:
+//     exp(-.5 (sd/ss)^2) * exp(-.5 (cd/sc)^2) = exp2(ks*(i^2+j^2) + kc*cd^2)
+// with ks = -.5*log2(e)/ss^2, kc = -.5*log2(e)/sc^2; the spatial term is wave-uniform.
+//
+// The texture and linear variants differ only in how the tile is addressed when it is filled
+// (2-D zero border vs flat index with row wrap-around), exactly the difference between
+// bialteral.comp:58-59 and bialteral_linear.comp:58.
+#include "common.hpp"
+
+namespace mid {
+
+struct BilArgs {
+    int w, h;
+    float ks, kc;          // exponent scales (log2 domain)
+    int tiles_x, tiles_y;
+    const void *in;
+    float4 *out;           // plain / fused-layers output
+    mid_weightinfo *W;     // layers accumulate mode
+    int n_layers;
+    const uint32_t *layers[16];
+};
+
+__device__ __forceinline__ unsigned xcd_remap_b(unsigned bid, unsigned nwg)
+{
+    const unsigned q = nwg >> 3, r = nwg & 7u, x = bid & 7u, i = bid >> 3;
+    return x * q + (x < r ? x : r) + i;
+}
+
+// MODE 0: plain bilateral (range weight and colour from `in`)
+// MODE 1: layers, accumulate one layer into W      (one dispatch of bialteral_layers.comp)
+// MODE 2: layers, all layers fused + normalize     (loop src/main.cpp:1610-1623 + normalize.comp)
+template <int R, int P, int NW, int FMT, bool LINEAR, int MODE>
+__global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
+{
+    constexpr int TILE_W = 64, TILE_H = NW * P;
+    constexpr int LW = TILE_W + 2 * R, LH = TILE_H + 2 * R;
+    constexpr int MR = P + 2 * R;   // tile rows a lane walks per column offset
+
+    extern __shared__ float4 lds[];
+    float4 *img_t = lds;                                  // colour source
+    float4 *gde_t = (MODE == 0) ? lds : lds + LW * LH;    // range-weight source (guide)
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned flat = xcd_remap_b(blockIdx.x, gridDim.x);
+    const int ty = (int)(flat / (unsigned)a.tiles_x), tx = (int)(flat - (unsigned)ty * a.tiles_x);
+    const int w = a.w, h = a.h;
+    const int X0 = tx * TILE_W, Y0 = ty * TILE_H;
+    const int gx = X0 + lane, yb = Y0 + wv * P;
+    const bool wave_active = yb < h;
+
+    fill_tile<FMT, LINEAR>(img_t, LW, LH, a.in, w, h, X0 - R, Y0 - R, tid, NW * 64);
+
+    // spatial exponent by |j|: ks * j^2 (wave-uniform)
+    float sj[R + 1];
+#pragma unroll
+    for (int j = 0; j <= R; ++j) sj[j] = a.ks * (float)(j * j);
+
+    float4 tot[P];
+    float totw[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) { tot[k] = make_float4(0.f, 0.f, 0.f, 0.f); totw[k] = 0.f; }
+
+    const int n_pass = (MODE == 2) ? a.n_layers : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        if (MODE != 0) {
+            __syncthreads();
+            fill_tile<MID_FMT_RGBA8, false>(gde_t, LW, LH, a.layers[pass], w, h, X0 - R, Y0 - R, tid, NW * 64);
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+
+        float cr[P], cg[P], cb[P];   // centre guide colour (texColor / layerColor)
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const float4 c = gde_t[(wv * P + k + R) * LW + lane + R];
+            cr[k] = c.x; cg[k] = c.y; cb[k] = c.z;
+        }
+        float4 acc[P];
+        float accw[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) { acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); accw[k] = 0.f; }
+
+        for (int i = -R; i <= R; ++i) {
+            const float si = a.ks * (float)(i * i);
+            float sij[R + 1];
+#pragma unroll
+            for (int j = 0; j <= R; ++j) sij[j] = si + sj[j];
+            const int base = (wv * P) * LW + lane + R + i;
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                // keep the compiler from hoisting every row's LDS read to the top of the
+                // iteration (VGPR blow-up at large radius): rows are consumed in groups of 8
+                if (m % 8 == 0 && m > 0) __builtin_amdgcn_sched_barrier(0);
+                const float4 g = gde_t[base + m * LW];
+                float4 c = g;
+                if (MODE != 0) c = img_t[base + m * LW];
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    const int j = m - R - k;               // row offset of this texel for output k
+                    if (j < -R || j > R) continue;
+                    const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    const float wt = __builtin_amdgcn_exp2f(fmaf(d2, a.kc, sij[j < 0 ? -j : j]));
+                    acc[k].x += c.x * wt; acc[k].y += c.y * wt;
+                    acc[k].z += c.z * wt; acc[k].w += c.w * wt;
+                    accw[k] += wt;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            tot[k].x += acc[k].x; tot[k].y += acc[k].y; tot[k].z += acc[k].z; tot[k].w += acc[k].w;
+            totw[k] += accw[k];
+        }
+    }
+
+    if (!wave_active || gx >= w) return;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const int gy = yb + k;
+        if (gy >= h) break;
+        const size_t idx = (size_t)gy * w + gx;
+        if (MODE == 0) {
+            a.out[idx] = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
+        } else if (MODE == 2) {
+            float4 o;
+            if (totw[k] == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);
+            else o = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
+            a.out[idx] = o;
+        } else {
+            float4 *wp = (float4 *)(a.W + idx);
+            float4 wc = wp[0], nw = wp[1];
+            wc.x += tot[k].x; wc.y += tot[k].y; wc.z += tot[k].z; wc.w += tot[k].w;
+            nw.x += totw[k];
+            wp[0] = wc; wp[1] = nw;
+        }
+    }
+}
+
+// Any radius without a tuned instantiation: one thread per pixel, global fetches.
+template <int FMT, bool LINEAR, int MODE>
+__global__ __launch_bounds__(256) void bilateral_generic_kernel(const BilArgs a, int R)
+{
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= a.w || y >= a.h) return;
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    float totw = 0.f;
+    const int n_pass = (MODE == 2) ? a.n_layers : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        float4 ctr;
+        if (MODE != 0) ctr = fetch_texture<MID_FMT_RGBA8>(a.layers[pass], a.w, a.h, x, y);
+        else ctr = LINEAR ? fetch_linear<FMT>(a.in, a.w, a.h, x, y) : fetch_texture<FMT>(a.in, a.w, a.h, x, y);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float accw = 0.f;
+        for (int j = -R; j <= R; ++j)
+            for (int i = -R; i <= R; ++i) {
+                float4 g, c;
+                if (MODE != 0) {
+                    g = fetch_texture<MID_FMT_RGBA8>(a.layers[pass], a.w, a.h, x + i, y + j);
+                    c = fetch_texture<FMT>(a.in, a.w, a.h, x + i, y + j);
+                } else {
+                    g = LINEAR ? fetch_linear<FMT>(a.in, a.w, a.h, x + i, y + j) : fetch_texture<FMT>(a.in, a.w, a.h, x + i, y + j);
+                    c = g;
+                }
+                const float dx = ctr.x - g.x, dy = ctr.y - g.y, dz = ctr.z - g.z;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const float wt = __builtin_amdgcn_exp2f(fmaf(d2, a.kc, a.ks * (float)(i * i + j * j)));
+                acc.x += c.x * wt; acc.y += c.y * wt; acc.z += c.z * wt; acc.w += c.w * wt;
+                accw += wt;
+            }
+        tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
+        totw += accw;
+    }
+    const size_t idx = (size_t)y * a.w + x;
+    if (MODE == 1) {
+        float4 *wp = (float4 *)(a.W + idx);
+        float4 wc = wp[0], nw = wp[1];
+        wc.x += tot.x; wc.y += tot.y; wc.z += tot.z; wc.w += tot.w;
+        nw.x += totw;
+        wp[0] = wc; wp[1] = nw;
+    } else {
+        float4 o;
+        if (MODE == 2 && totw == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);
+        else o = make_float4(tot.x / totw, tot.y / totw, tot.z / totw, tot.w / totw);
+        a.out[idx] = o;
+    }
+}
+
+template <int R, int P, int NW, int FMT, bool LINEAR, int MODE>
+static int launch_tiled(mid_ctx *ctx, BilArgs &a, hipStream_t s)
+{
+    constexpr int LW = 64 + 2 * R, LH = NW * P + 2 * R;
+    constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float4) * (MODE == 0 ? 1 : 2);
+    auto kern = bilateral_kernel<R, P, NW, FMT, LINEAR, MODE>;
+    if ((int)lds_bytes > ctx->lds_max)
+        return set_error(MID_ERR_UNSUPPORTED, "bilateral tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
+    static thread_local const void *configured = nullptr;
+    if (configured != (const void *)kern) {
+        MID_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        configured = (const void *)kern;
+    }
+    a.tiles_x = (int)cdiv(a.w, 64);
+    a.tiles_y = (int)cdiv(a.h, NW * P);
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles_x * a.tiles_y), dim3(NW * 64), lds_bytes, s, a);
+    MID_HIP(hipGetLastError());
+    return MID_OK;
+}
+
+template <int FMT, bool LINEAR, int MODE>
+static int dispatch_radius(mid_ctx *ctx, int radius, BilArgs &a, hipStream_t s)
+{
+    switch (radius) {
+    case 4:  return launch_tiled<4, 4, 4, FMT, LINEAR, MODE>(ctx, a, s);    // BASELINE config 1 window
+    case 8:  return launch_tiled<8, 4, 4, FMT, LINEAR, MODE>(ctx, a, s);    // BASELINE configs 2 and 4
+    case 10: return launch_tiled<10, 4, 4, FMT, LINEAR, MODE>(ctx, a, s);   // CPU path window, src/main.cpp:1819
+    case 20: return launch_tiled<20, 4, 8, FMT, LINEAR, MODE>(ctx, a, s);   // TEXEL_WINDOW as shipped
+    default: break;
+    }
+    dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16));
+    hipLaunchKernelGGL((bilateral_generic_kernel<FMT, LINEAR, MODE>), grid, dim3(256), 0, s, a, radius);
+    MID_HIP(hipGetLastError());
+    return MID_OK;
+}
+
+static int check_params(const mid_bilateral_params *p, const char *who)
+{
+    MID_REQUIRE(p != nullptr, "%s: params is NULL", who);
+    MID_REQUIRE(p->width > 0 && p->height > 0, "%s: bad size %dx%d", who, p->width, p->height);
+    MID_REQUIRE((long)p->width * p->height < (1l << 30), "%s: image too large", who);
+    MID_REQUIRE(p->spatialSigma > 0.f && p->colorSigma > 0.f, "%s: sigmas must be > 0", who);
+    MID_REQUIRE(p->radius >= 1 && p->radius <= 24, "%s: radius %d outside 1..24", who, p->radius);
+    MID_REQUIRE(p->format == MID_FMT_RGBA32F || p->format == MID_FMT_RGBA8, "%s: unknown format %d", who, p->format);
+    MID_REQUIRE(p->layout == MID_LAYOUT_TEXTURE || p->layout == MID_LAYOUT_LINEAR, "%s: unknown layout %d", who, p->layout);
+    return MID_OK;
+}
+
+static void fill_scales(const mid_bilateral_params *p, BilArgs &a)
+{
+    a.w = p->width; a.h = p->height;
+    a.ks = (float)(-0.5 * 1.4426950408889634 / ((double)p->spatialSigma * (double)p->spatialSigma));
+    a.kc = (float)(-0.5 * 1.4426950408889634 / ((double)p->colorSigma * (double)p->colorSigma));
+}
+
+}  // namespace mid
+
+using namespace mid;
+
+extern "C" int mid_bilateral(mid_ctx *ctx, const mid_bilateral_params *p, const void *in,
+                             mid_pixel *out, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    if (int rc = check_params(p, "bilateral")) return rc;
+    MID_REQUIRE(in && out, "bilateral: NULL image pointer");
+    MID_REQUIRE((const void *)in != (const void *)out, "bilateral: in-place filtering is not supported");
+    BilArgs a{};
+    fill_scales(p, a);
+    a.in = in; a.out = (float4 *)out;
+    const bool lin = p->layout == MID_LAYOUT_LINEAR, u8 = p->format == MID_FMT_RGBA8;
+    if (lin) return u8 ? dispatch_radius<MID_FMT_RGBA8, true, 0>(ctx, p->radius, a, b.s)
+                       : dispatch_radius<MID_FMT_RGBA32F, true, 0>(ctx, p->radius, a, b.s);
+    return u8 ? dispatch_radius<MID_FMT_RGBA8, false, 0>(ctx, p->radius, a, b.s)
+              : dispatch_radius<MID_FMT_RGBA32F, false, 0>(ctx, p->radius, a, b.s);
+}
+
+extern "C" int mid_bilateral_layers_accum(mid_ctx *ctx, const mid_bilateral_params *p, const void *in,
+                                          const uint32_t *layer, mid_weightinfo *W, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    if (int rc = check_params(p, "bilateral_layers_accum")) return rc;
+    MID_REQUIRE(in && layer && W, "bilateral_layers_accum: NULL pointer");
+    // NLM/layers are only ever bound to textures in the reference (src/main.cpp:1406-1428).
+    MID_REQUIRE(p->layout == MID_LAYOUT_TEXTURE, "bilateral_layers_accum: layers exist for the texture layout only");
+    BilArgs a{};
+    fill_scales(p, a);
+    a.in = in; a.W = W; a.n_layers = 1; a.layers[0] = layer;
+    return p->format == MID_FMT_RGBA8 ? dispatch_radius<MID_FMT_RGBA8, false, 1>(ctx, p->radius, a, b.s)
+                                      : dispatch_radius<MID_FMT_RGBA32F, false, 1>(ctx, p->radius, a, b.s);
+}
+
+extern "C" int mid_bilateral_layers(mid_ctx *ctx, const mid_bilateral_params *p, const void *in,
+                                    const uint32_t *const *layers, int n_layers, mid_pixel *out, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    if (int rc = check_params(p, "bilateral_layers")) return rc;
+    MID_REQUIRE(in && layers && out, "bilateral_layers: NULL pointer");
+    MID_REQUIRE(p->layout == MID_LAYOUT_TEXTURE, "bilateral_layers: layers exist for the texture layout only");
+    MID_REQUIRE(n_layers >= 0 && n_layers <= 16, "bilateral_layers: n_layers %d outside 0..16", n_layers);
+    BilArgs a{};
+    fill_scales(p, a);
+    a.in = in; a.out = (float4 *)out; a.n_layers = n_layers;
+    for (int i = 0; i < n_layers; ++i) {
+        MID_REQUIRE(layers[i] != nullptr, "bilateral_layers: layer %d is NULL", i);
+        a.layers[i] = layers[i];
+    }
+    return p->format == MID_FMT_RGBA8 ? dispatch_radius<MID_FMT_RGBA8, false, 2>(ctx, p->radius, a, b.s)
+                                      : dispatch_radius<MID_FMT_RGBA32F, false, 2>(ctx, p->radius, a, b.s);
+}

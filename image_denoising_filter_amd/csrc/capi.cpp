@@ -1,0 +1,208 @@
+// capi.cpp -- context, error, memory and timer entry points of libmi_denoise.so.
+// Replaces the Vulkan bootstrap and buffer factories of the reference
+// (src/vk_utils.cpp:13-305, src/main.cpp:247-401) with plain HIP: a context is a device
+// plus three streams (compute / upload / download).
+#include "common.hpp"
+
+namespace mid {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+Bind::Bind(mid_ctx *ctx, void *stream) : rc(MID_OK), s(nullptr)
+{
+    if (!ctx) { rc = set_error(MID_ERR_INVALID, "context is NULL"); return; }
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) { rc = set_error(MID_ERR_HIP, "hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e)); return; }
+    s = stream ? (hipStream_t)stream : ctx->compute;
+}
+
+}  // namespace mid
+
+using namespace mid;
+
+extern "C" const char *mid_last_error(void) { return g_err; }
+extern "C" int mid_version(void) { return MID_VERSION; }
+
+extern "C" int mid_ctx_create(int device, mid_ctx **out)
+{
+    MID_REQUIRE(out != nullptr, "ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_error(MID_ERR_NO_DEVICE, "no HIP device available (%s): mi_denoise has no CPU path",
+                         e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    MID_REQUIRE(device >= 0 && device < n, "ctx_create: device %d outside 0..%d", device, n - 1);
+    MID_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MID_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(MID_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
+    mid_ctx *c = new mid_ctx();
+    c->device = device;
+    c->cu_count = prop.multiProcessorCount;
+    c->lds_max = (int)prop.sharedMemPerBlockOptin > 0 ? (int)prop.sharedMemPerBlockOptin : (int)prop.sharedMemPerBlock;
+    if (c->lds_max < 160 * 1024 && (int)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024) c->lds_max = 160 * 1024;
+    snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+    if (hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->upload, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->download, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return set_error(MID_ERR_HIP, "ctx_create: stream creation failed");
+    }
+    *out = c;
+    return MID_OK;
+}
+
+extern "C" void mid_ctx_destroy(mid_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->compute);
+    (void)hipStreamSynchronize(ctx->upload);
+    (void)hipStreamSynchronize(ctx->download);
+    (void)hipStreamDestroy(ctx->compute);
+    (void)hipStreamDestroy(ctx->upload);
+    (void)hipStreamDestroy(ctx->download);
+    delete ctx;
+}
+
+extern "C" int mid_device_name(mid_ctx *ctx, char *buf, size_t buflen)
+{
+    MID_REQUIRE(ctx && buf && buflen > 0, "device_name: bad argument");
+    snprintf(buf, buflen, "%s", ctx->name);
+    return MID_OK;
+}
+
+extern "C" int mid_alloc(mid_ctx *ctx, size_t bytes, void **dptr)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(dptr && bytes > 0, "alloc: bad argument");
+    MID_HIP(hipMalloc(dptr, bytes));
+    return MID_OK;
+}
+
+extern "C" int mid_free(mid_ctx *ctx, void *dptr)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    if (dptr) MID_HIP(hipFree(dptr));
+    return MID_OK;
+}
+
+extern "C" int mid_alloc_host(mid_ctx *ctx, size_t bytes, void **hptr)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(hptr && bytes > 0, "alloc_host: bad argument");
+    MID_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return MID_OK;
+}
+
+extern "C" int mid_free_host(mid_ctx *ctx, void *hptr)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    if (hptr) MID_HIP(hipHostFree(hptr));
+    return MID_OK;
+}
+
+extern "C" int mid_memcpy_h2d(mid_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(dst && src, "memcpy_h2d: NULL pointer");
+    MID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b.s));
+    return MID_OK;
+}
+
+extern "C" int mid_memcpy_d2h(mid_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(dst && src, "memcpy_d2h: NULL pointer");
+    MID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b.s));
+    return MID_OK;
+}
+
+extern "C" int mid_memset(mid_ctx *ctx, void *dst, int value, size_t bytes, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(dst, "memset: NULL pointer");
+    MID_HIP(hipMemsetAsync(dst, value, bytes, b.s));
+    return MID_OK;
+}
+
+extern "C" int mid_stream_sync(mid_ctx *ctx, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    MID_HIP(hipStreamSynchronize(b.s));
+    return MID_OK;
+}
+
+// ---- timers -------------------------------------------------------------------------------
+struct mid_timer {
+    mid_ctx *ctx;
+    hipEvent_t a, b;
+};
+
+extern "C" int mid_timer_create(mid_ctx *ctx, mid_timer **out)
+{
+    Bind bd(ctx, nullptr);
+    if (bd.rc) return bd.rc;
+    MID_REQUIRE(out, "timer_create: out is NULL");
+    mid_timer *t = new mid_timer{ctx, nullptr, nullptr};
+    if (hipEventCreate(&t->a) != hipSuccess || hipEventCreate(&t->b) != hipSuccess) {
+        delete t;
+        return set_error(MID_ERR_HIP, "timer_create: hipEventCreate failed");
+    }
+    *out = t;
+    return MID_OK;
+}
+
+extern "C" int mid_timer_destroy(mid_timer *t)
+{
+    if (!t) return MID_OK;
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+    return MID_OK;
+}
+
+extern "C" int mid_timer_tick(mid_timer *t, void *stream)
+{
+    MID_REQUIRE(t, "timer_tick: NULL timer");
+    Bind b(t->ctx, stream);
+    if (b.rc) return b.rc;
+    MID_HIP(hipEventRecord(t->a, b.s));
+    return MID_OK;
+}
+
+extern "C" int mid_timer_tock(mid_timer *t, void *stream)
+{
+    MID_REQUIRE(t, "timer_tock: NULL timer");
+    Bind b(t->ctx, stream);
+    if (b.rc) return b.rc;
+    MID_HIP(hipEventRecord(t->b, b.s));
+    return MID_OK;
+}
+
+extern "C" int mid_timer_ms(mid_timer *t, float *ms)
+{
+    MID_REQUIRE(t && ms, "timer_ms: NULL argument");
+    MID_HIP(hipEventSynchronize(t->b));
+    MID_HIP(hipEventElapsedTime(ms, t->a, t->b));
+    return MID_OK;
+}

@@ -1,0 +1,362 @@
+// nlm.hip -- non-local means for gfx950 (replaces shaders/nonlocal.comp:28-72).
+//
+// Algorithm.  For target pixel p and search offset s the reference evaluates
+//     d(p,s) = sum_{o in patch} |T(p+o) - Nb(p+s+o)|^2_rgb,   wt = exp(-d/h^2)
+// by brute force (SW^2 * PW^2 texel pairs per pixel).  Here d(p,s) is the PW x PW box sum of
+// the per-offset difference image D_s(q) = |T(q) - Nb(q+s)|^2, so every D_s(q) is computed
+// once and shared by the PW^2 pixels whose patch covers q:
+//   * a wave owns 64 adjacent columns x R rows; lane l owns one column, keeps its target
+//     column strip T(q) in VGPRs for the whole kernel and reads Nb(q+s) from an LDS tile
+//     (float4 per texel: one conflict-free ds_read_b128 per texel);
+//   * the vertical PW-tap sums are formed in registers with shared pair/quad partial sums;
+//   * the horizontal PW-tap sums move across lanes with whole-wave DPP shifts fused into
+//     v_add_f32 (no LDS traffic, no shuffles): 64-(PW-1) lanes hold finished patch distances;
+//   * v_exp_f32 with the -log2(e)/h^2 factor folded in, then 4 FMAs + 1 add per (pixel,offset).
+// All sums are of non-negative terms (no running-sum cancellation), so results agree with
+// the reference order to a few ulp of the patch distance.
+//
+// Out-of-image texels are vec4(0) for both images (LDS halo zero-filled).
+#include "common.hpp"
+
+namespace mid {
+
+struct NlmArgs {
+    int w, h;
+    float kexp;            // -log2(e) / h^2
+    int tiles_x, tiles_y;
+    // accumulate mode (one dispatch of nonlocal.comp)
+    const void *target;
+    const void *neighbour;
+    mid_weightinfo *W;
+    // fused temporal mode
+    int n_frames, k, first, count;
+    FrameTable frames;
+    OutTable outs;
+};
+
+template <int PW, int R>
+__device__ __forceinline__ void vertical_box(const float (&D)[R + PW - 1], float (&V)[R])
+{
+    if constexpr (PW == 7 || PW == 6) {
+        float P[R + 4];
+#pragma unroll
+        for (int m = 0; m < R + 4; ++m) P[m] = D[m] + D[m + 1];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const float q = P[k] + P[k + 2];
+            if constexpr (PW == 7) V[k] = (q + P[k + 4]) + D[k + 6];
+            else                   V[k] = q + P[k + 4];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            float s = D[k];
+#pragma unroll
+            for (int j = 1; j < PW; ++j) s += D[k + j];
+            V[k] = s;
+        }
+    }
+}
+
+// H[l] = sum_{i=PLO}^{PHI-1} V[l+i] across lanes; valid for lanes -PLO .. 63-(PHI-1).
+template <int PLO, int PHI>
+__device__ __forceinline__ float horizontal_box(float v)
+{
+    constexpr int NL = -PLO, NR = PHI - 1;
+    float c = v;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) c = v + wave_shl1(c);          // v[l .. l+NR]
+    if constexpr (NL > 0) {
+        float b = v;
+#pragma unroll
+        for (int i = 0; i < NL - 1; ++i) b = v + wave_shr1(b);  // v[l-(NL-1) .. l]
+        c = c + wave_shr1(b);                                   // + v[l-NL .. l-1]
+    }
+    return c;
+}
+
+// XCD-aware bijective remap of the flat workgroup id: workgroups are dealt round-robin over
+// the 8 XCDs, so give each XCD one contiguous chunk of tiles (neighbouring tiles share halo
+// texels in that XCD's L2).  Speed only; any placement is correct.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
+{
+    const unsigned q = nwg >> 3, r = nwg & 7u, x = bid & 7u, i = bid >> 3;
+    return x * q + (x < r ? x : r) + i;
+}
+
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED>
+__global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
+{
+    constexpr int SW = SHI - SLO, PW = PHI - PLO;
+    constexpr int DR = R + PW - 1;
+    constexpr int NL = -PLO, NR = PHI - 1;
+    constexpr int VW = 64 - (PW - 1);
+    constexpr int TILE_H = NW * R;
+    constexpr int LW = 64 + SW - 1;
+    constexpr int LH = TILE_H + PW - 1 + SW - 1;
+    static_assert(PLO <= 0 && PHI >= 1 && SW >= 1, "ranges must contain 0");
+
+    extern __shared__ float4 lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned tiles = (unsigned)(a.tiles_x * a.tiles_y);
+    const unsigned flat = xcd_remap(blockIdx.x, gridDim.x);
+    const int fz = (int)(flat / tiles);
+    const unsigned trem = flat - (unsigned)fz * tiles;
+    const int ty = (int)(trem / (unsigned)a.tiles_x), tx = (int)(trem - (unsigned)ty * a.tiles_x);
+
+    const int w = a.w, h = a.h;
+    const int X0 = tx * VW, Y0 = ty * TILE_H;
+    const int gx = X0 + PLO + lane;          // column owned by this lane
+    const int yb = Y0 + wv * R;              // first output row of this wave
+    const bool wave_active = yb < h;
+
+    const int t_out = a.first + fz;          // FUSED: output frame
+    const void *target = FUSED ? a.frames.p[t_out] : a.target;
+    int f_lo = 0, f_hi = 0;
+    if (FUSED) {
+        f_lo = t_out - a.k < 0 ? 0 : t_out - a.k;
+        f_hi = t_out + a.k > a.n_frames - 1 ? a.n_frames - 1 : t_out + a.k;
+    }
+
+    // Target column strip, kept in registers for every offset and every neighbour frame.
+    float Tr[DR], Tg[DR], Tb[DR];
+#pragma unroll
+    for (int m = 0; m < DR; ++m) {
+        const float4 t = fetch_texture<FMT>(target, w, h, gx, yb + PLO + m);
+        Tr[m] = t.x; Tg[m] = t.y; Tb[m] = t.z;
+    }
+
+    float4 tot[R];
+    float totw[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) { tot[k] = make_float4(0.f, 0.f, 0.f, 0.f); totw[k] = 0.f; }
+
+    for (int f = f_lo; f <= f_hi; ++f) {
+        const void *nb = FUSED ? a.frames.p[f] : a.neighbour;
+        __syncthreads();   // previous frame's readers are done with the tile
+        fill_tile<FMT, false>(lds, LW, LH, nb, w, h, X0 + PLO + SLO, Y0 + PLO + SLO, tid, NW * 64);
+        __syncthreads();
+        if (!wave_active) continue;
+
+        float4 acc[R];
+        float accw[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) { acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); accw[k] = 0.001f; }  // nonlocal.comp:32-33
+
+        for (int sy = 0; sy < SW; ++sy) {
+            const float4 *rowp = lds + (wv * R + sy) * LW + lane;
+            for (int sx = 0; sx < SW; ++sx) {
+                const float4 *p = rowp + sx;
+                float D[DR];
+                float4 c[R];
+#pragma unroll
+                for (int m = 0; m < DR; ++m) {
+                    const float4 n = p[m * LW];
+                    const float dx = Tr[m] - n.x, dy = Tg[m] - n.y, dz = Tb[m] - n.z;
+                    D[m] = dx * dx + dy * dy + dz * dz;
+                    if (m >= NL && m < NL + R) c[m - NL] = n;   // centre texel Nb(p+s) of output row m-NL
+                }
+                float V[R];
+                vertical_box<PW, R>(D, V);
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const float d = horizontal_box<PLO, PHI>(V[k]);
+                    const float wt = __builtin_amdgcn_exp2f(d * a.kexp);   // exp(-d/h^2), nonlocal.comp:55
+                    acc[k].x += c[k].x * wt; acc[k].y += c[k].y * wt;      // :56
+                    acc[k].z += c[k].z * wt; acc[k].w += c[k].w * wt;
+                    accw[k] += wt;                                         // :57
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {   // nlmData[p] += ..., nonlocal.comp:61-62
+            tot[k].x += acc[k].x; tot[k].y += acc[k].y; tot[k].z += acc[k].z; tot[k].w += acc[k].w;
+            totw[k] += accw[k];
+        }
+    }
+
+    if (!wave_active || lane < NL || lane > 63 - NR || gx >= w) return;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int gy = yb + k;
+        if (gy >= h) break;
+        const size_t idx = (size_t)gy * w + gx;
+        if (FUSED) {
+            float4 o;
+            if (totw[k] == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);       // normalize.comp:36-38
+            else o = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
+            ((float4 *)a.outs.p[fz])[idx] = o;
+        } else {
+            float4 *wp = (float4 *)(a.W + idx);
+            float4 wc = wp[0], nw = wp[1];
+            wc.x += tot[k].x; wc.y += tot[k].y; wc.z += tot[k].z; wc.w += tot[k].w;
+            nw.x += totw[k];
+            wp[0] = wc;
+            wp[1] = nw;
+        }
+    }
+}
+
+// Any other search/patch ranges: one thread per pixel, straight from the shader text
+// (nonlocal.comp:36-59) with global-memory fetches.  Correct for every legal parameter set;
+// not a tuned path.
+template <int FMT, bool FUSED>
+__global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int slo, int shi, int plo, int phi)
+{
+    const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (px >= a.w || py >= a.h) return;
+    const int fz = blockIdx.z, t_out = a.first + fz;
+    const void *target = FUSED ? a.frames.p[t_out] : a.target;
+    int f_lo = 0, f_hi = 0;
+    if (FUSED) {
+        f_lo = t_out - a.k < 0 ? 0 : t_out - a.k;
+        f_hi = t_out + a.k > a.n_frames - 1 ? a.n_frames - 1 : t_out + a.k;
+    }
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    float totw = 0.f;
+    for (int f = f_lo; f <= f_hi; ++f) {
+        const void *nb = FUSED ? a.frames.p[f] : a.neighbour;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float accw = 0.001f;
+        for (int y = py + slo; y < py + shi; ++y)
+            for (int x = px + slo; x < px + shi; ++x) {
+                float d = 0.f;
+                for (int j = plo; j < phi; ++j)
+                    for (int i = plo; i < phi; ++i) {
+                        const float4 t = fetch_texture<FMT>(target, a.w, a.h, px + i, py + j);
+                        const float4 n = fetch_texture<FMT>(nb, a.w, a.h, x + i, y + j);
+                        const float dx = t.x - n.x, dy = t.y - n.y, dz = t.z - n.z;
+                        d += dx * dx + dy * dy + dz * dz;
+                    }
+                const float wt = __builtin_amdgcn_exp2f(d * a.kexp);
+                const float4 c = fetch_texture<FMT>(nb, a.w, a.h, x, y);
+                acc.x += c.x * wt; acc.y += c.y * wt; acc.z += c.z * wt; acc.w += c.w * wt;
+                accw += wt;
+            }
+        tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
+        totw += accw;
+    }
+    const size_t idx = (size_t)py * a.w + px;
+    if (FUSED) {
+        float4 o;
+        if (totw == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);
+        else o = make_float4(tot.x / totw, tot.y / totw, tot.z / totw, tot.w / totw);
+        ((float4 *)a.outs.p[fz])[idx] = o;
+    } else {
+        float4 *wp = (float4 *)(a.W + idx);
+        float4 wc = wp[0], nw = wp[1];
+        wc.x += tot.x; wc.y += tot.y; wc.z += tot.z; wc.w += tot.w;
+        nw.x += totw;
+        wp[0] = wc; wp[1] = nw;
+    }
+}
+
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED>
+static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
+{
+    constexpr int SW = SHI - SLO, PW = PHI - PLO;
+    constexpr int VW = 64 - (PW - 1), TILE_H = NW * R;
+    constexpr int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + SW - 1;
+    constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
+    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED>;
+    if ((int)lds_bytes > ctx->lds_max)
+        return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
+    static thread_local const void *configured = nullptr;   // per-thread, per-instantiation
+    if (configured != (const void *)kern) {
+        MID_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        configured = (const void *)kern;
+    }
+    a.tiles_x = (int)cdiv(a.w, VW);
+    a.tiles_y = (int)cdiv(a.h, TILE_H);
+    const unsigned nwg = (unsigned)a.tiles_x * a.tiles_y * (FUSED ? a.count : 1);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NW * 64), lds_bytes, s, a);
+    MID_HIP(hipGetLastError());
+    return MID_OK;
+}
+
+template <int FMT, bool FUSED>
+static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s)
+{
+    if (p->search_lo == -10 && p->search_hi == 11 && p->patch_lo == -3 && p->patch_hi == 4)
+        return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED>(ctx, a, s);    // 21x21 / 7x7 (benchmark)
+    if (p->search_lo == -7 && p->search_hi == 7 && p->patch_lo == -3 && p->patch_hi == 3)
+        return launch_strip<-7, 7, -3, 3, 8, 8, FMT, FUSED>(ctx, a, s);      // nonlocal.comp:5-6 as shipped
+    dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16), FUSED ? a.count : 1);
+    hipLaunchKernelGGL((nlm_generic_kernel<FMT, FUSED>), grid, dim3(256), 0, s, a,
+                       p->search_lo, p->search_hi, p->patch_lo, p->patch_hi);
+    MID_HIP(hipGetLastError());
+    return MID_OK;
+}
+
+static int check_params(const mid_nlm_params *p)
+{
+    MID_REQUIRE(p != nullptr, "nlm: params is NULL");
+    MID_REQUIRE(p->width > 0 && p->height > 0, "nlm: bad size %dx%d", p->width, p->height);
+    MID_REQUIRE((long)p->width * p->height < (1l << 30), "nlm: image too large");
+    MID_REQUIRE(p->filteringParameter > 0.f, "nlm: filteringParameter must be > 0");
+    MID_REQUIRE(p->search_lo <= 0 && p->search_hi >= 1 && p->patch_lo <= 0 && p->patch_hi >= 1,
+                "nlm: half-open ranges [lo,hi) must contain 0");
+    MID_REQUIRE(p->search_hi - p->search_lo <= 64 && p->patch_hi - p->patch_lo <= 16, "nlm: window too large");
+    MID_REQUIRE(p->format == MID_FMT_RGBA32F || p->format == MID_FMT_RGBA8, "nlm: unknown format %d", p->format);
+    return MID_OK;
+}
+
+static float kexp_of(float hparam)
+{
+    return (float)(-1.4426950408889634 / ((double)hparam * (double)hparam));
+}
+
+}  // namespace mid
+
+using namespace mid;
+
+extern "C" int mid_nlm_accum(mid_ctx *ctx, const mid_nlm_params *p, const void *target,
+                             const void *neighbour, mid_weightinfo *W, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    if (int rc = check_params(p)) return rc;
+    MID_REQUIRE(target && neighbour && W, "nlm_accum: NULL image pointer");
+    NlmArgs a{};
+    a.w = p->width; a.h = p->height; a.kexp = kexp_of(p->filteringParameter);
+    a.target = target; a.neighbour = neighbour; a.W = W;
+    a.n_frames = 1; a.k = 0; a.first = 0; a.count = 1;
+    if (p->format == MID_FMT_RGBA8) return dispatch_ranges<MID_FMT_RGBA8, false>(ctx, p, a, b.s);
+    return dispatch_ranges<MID_FMT_RGBA32F, false>(ctx, p, a, b.s);
+}
+
+extern "C" int mid_nlm_temporal(mid_ctx *ctx, const mid_nlm_params *p, const void *const *frames,
+                                int n_frames, int k, int first, int count, mid_pixel *const *out,
+                                void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    if (int rc = check_params(p)) return rc;
+    MID_REQUIRE(frames && out, "nlm_temporal: NULL table");
+    MID_REQUIRE(n_frames >= 1 && k >= 0 && count >= 1 && first >= 0 && first + count <= n_frames,
+                "nlm_temporal: bad frame range (n=%d k=%d first=%d count=%d)", n_frames, k, first, count);
+    // Output frames are processed in chunks so that chunk + halo fits the by-value frame table.
+    const int max_chunk = kMaxFrames - 2 * k;
+    MID_REQUIRE(max_chunk >= 1, "nlm_temporal: k=%d too large", k);
+    for (int c0 = first; c0 < first + count; c0 += max_chunk) {
+        const int cn = (first + count - c0) < max_chunk ? (first + count - c0) : max_chunk;
+        const int lo = c0 - k < 0 ? 0 : c0 - k;
+        const int hi = c0 + cn - 1 + k > n_frames - 1 ? n_frames - 1 : c0 + cn - 1 + k;
+        NlmArgs a{};
+        a.w = p->width; a.h = p->height; a.kexp = kexp_of(p->filteringParameter);
+        a.n_frames = hi - lo + 1; a.k = k; a.first = c0 - lo; a.count = cn;
+        for (int f = lo; f <= hi; ++f) {
+            MID_REQUIRE(frames[f] != nullptr, "nlm_temporal: frame %d is NULL", f);
+            a.frames.p[f - lo] = frames[f];
+        }
+        for (int t = 0; t < cn; ++t) {
+            MID_REQUIRE(out[c0 - first + t] != nullptr, "nlm_temporal: out %d is NULL", c0 - first + t);
+            a.outs.p[t] = out[c0 - first + t];
+        }
+        int rc = (p->format == MID_FMT_RGBA8) ? dispatch_ranges<MID_FMT_RGBA8, true>(ctx, p, a, b.s)
+                                              : dispatch_ranges<MID_FMT_RGBA32F, true>(ctx, p, a, b.s);
+        if (rc) return rc;
+    }
+    return MID_OK;
+}

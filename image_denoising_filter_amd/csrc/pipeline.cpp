@@ -1,0 +1,136 @@
+// pipeline.cpp -- the frame pipeline: host frames in, denoised host frames out.
+//
+// Replaces the reference's single-queue ping-pong (RecordCommandsOfOverlappingNLM,
+// src/main.cpp:889-989, loop :1539-1573: one command buffer holding "dispatch on texture A"
+// followed, without a barrier, by "copy staging -> texture B", descriptor sets swapped by
+// parity, and a fence wait after every submit).  Here three HIP streams run concurrently:
+//
+//   upload   : hipMemcpyAsync host frame f -> device ring slot f % RING
+//   compute  : temporal NLM of output frame t over ring slots t-k..t+k
+//   download : hipMemcpyAsync device out slot t % 2 -> host
+//
+// joined only by events: compute(t) waits for upload(t+k); upload(f) waits for the last
+// compute that still reads the slot it overwrites; download(t) waits for compute(t);
+// compute(t) waits for download(t-2) before reusing an output slot.  The ring holds 2k+2
+// frames, so frame t+k+1 streams in over PCIe while frame t is being filtered.  Host frames
+// allocated with mid_alloc_host (pinned) are DMA'd directly; pageable memory still works but
+// HIP stages it and the overlap is lost.
+//
+// Frame selection differs from the reference on purpose: frames are taken
+// in the order given, window t-k..t+k clipped at the sequence ends; the reference's "every
+// file of the directory in directory order, target twice, last frame never filtered" is not
+// reproduced.
+#include "common.hpp"
+#include <chrono>
+#include <vector>
+
+using namespace mid;
+
+namespace {
+
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    ~EventPool() { for (auto e : ev) (void)hipEventDestroy(e); }
+    int make(size_t n)
+    {
+        ev.resize(n, nullptr);
+        for (auto &e : ev) MID_HIP(hipEventCreate(&e));
+        return MID_OK;
+    }
+};
+
+struct DeviceBufs {
+    std::vector<void *> p;
+    ~DeviceBufs() { for (auto q : p) (void)hipFree(q); }
+    int make(size_t n, size_t bytes)
+    {
+        p.assign(n, nullptr);
+        for (auto &q : p) MID_HIP(hipMalloc(&q, bytes));
+        return MID_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
+                                int n, int k, mid_pixel *const *host_out, int overlap, float *timings_ms)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(p && host_frames && host_out, "sequence_nlm: NULL argument");
+    MID_REQUIRE(n >= 1 && k >= 0 && 2 * k + 2 <= kMaxFrames, "sequence_nlm: bad n=%d k=%d", n, k);
+    MID_REQUIRE(p->width > 0 && p->height > 0, "sequence_nlm: bad size");
+    for (int i = 0; i < n; ++i) MID_REQUIRE(host_frames[i] && host_out[i], "sequence_nlm: frame %d is NULL", i);
+
+    const size_t npix = (size_t)p->width * p->height;
+    const size_t in_bytes = npix * (p->format == MID_FMT_RGBA8 ? 4 : 16), out_bytes = npix * 16;
+    const int ring = n < 2 * k + 2 ? n : 2 * k + 2;
+
+    DeviceBufs dring, dout;
+    if (int rc = dring.make(ring, in_bytes)) return rc;
+    if (int rc = dout.make(2, out_bytes)) return rc;
+    EventPool up0, up1, c0, c1, d0, d1;
+    for (EventPool *e : {&up0, &up1, &c0, &c1, &d0, &d1})
+        if (int rc = e->make(n)) return rc;
+
+    const auto wall0 = std::chrono::steady_clock::now();
+    int next_upload = 0;
+    auto upload = [&](int f) -> int {
+        if (f >= ring) {   // the slot still holds frame f-ring, last read by output (f-ring)+k
+            const int last_reader = f - ring + k < n - 1 ? f - ring + k : n - 1;
+            MID_HIP(hipStreamWaitEvent(ctx->upload, c1.ev[last_reader], 0));
+        }
+        MID_HIP(hipEventRecord(up0.ev[f], ctx->upload));
+        MID_HIP(hipMemcpyAsync(dring.p[f % ring], host_frames[f], in_bytes, hipMemcpyHostToDevice, ctx->upload));
+        MID_HIP(hipEventRecord(up1.ev[f], ctx->upload));
+        return MID_OK;
+    };
+
+    for (int t = 0; t < n; ++t) {
+        const int need = t + k < n - 1 ? t + k : n - 1;
+        const int ahead = overlap ? (need + 1 < n - 1 ? need + 1 : n - 1) : need;
+        // frames up to t+k must be resident; with overlap also start frame t+k+1 now, it only
+        // waits for compute(t-1) and then runs beside compute(t)
+        while (next_upload <= need) { if (int rc = upload(next_upload++)) return rc; }
+        MID_HIP(hipStreamWaitEvent(ctx->compute, up1.ev[need], 0));
+        if (t >= 2) MID_HIP(hipStreamWaitEvent(ctx->compute, d1.ev[t - 2], 0));
+
+        const int lo = t - k < 0 ? 0 : t - k;
+        const void *tbl[kMaxFrames];
+        for (int f = lo; f <= need; ++f) tbl[f - lo] = dring.p[f % ring];
+        mid_pixel *o = (mid_pixel *)dout.p[t & 1];
+        MID_HIP(hipEventRecord(c0.ev[t], ctx->compute));
+        if (int rc = mid_nlm_temporal(ctx, p, tbl, need - lo + 1, k, t - lo, 1, &o, ctx->compute)) return rc;
+        MID_HIP(hipEventRecord(c1.ev[t], ctx->compute));
+
+        while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }
+
+        MID_HIP(hipStreamWaitEvent(ctx->download, c1.ev[t], 0));
+        MID_HIP(hipEventRecord(d0.ev[t], ctx->download));
+        MID_HIP(hipMemcpyAsync(host_out[t], dout.p[t & 1], out_bytes, hipMemcpyDeviceToHost, ctx->download));
+        MID_HIP(hipEventRecord(d1.ev[t], ctx->download));
+
+        if (!overlap) {   // the reference's behaviour: a fence wait after every submit (src/main.cpp:1092)
+            MID_HIP(hipStreamSynchronize(ctx->upload));
+            MID_HIP(hipStreamSynchronize(ctx->compute));
+            MID_HIP(hipStreamSynchronize(ctx->download));
+        }
+    }
+    MID_HIP(hipStreamSynchronize(ctx->upload));
+    MID_HIP(hipStreamSynchronize(ctx->compute));
+    MID_HIP(hipStreamSynchronize(ctx->download));
+    const auto wall1 = std::chrono::steady_clock::now();
+
+    if (timings_ms) {
+        float kern = 0.f, copy = 0.f, ms = 0.f;
+        for (int t = 0; t < n; ++t) {
+            MID_HIP(hipEventElapsedTime(&ms, c0.ev[t], c1.ev[t])); kern += ms;
+            MID_HIP(hipEventElapsedTime(&ms, up0.ev[t], up1.ev[t])); copy += ms;
+            MID_HIP(hipEventElapsedTime(&ms, d0.ev[t], d1.ev[t])); copy += ms;
+        }
+        timings_ms[0] = std::chrono::duration<float, std::milli>(wall1 - wall0).count();
+        timings_ms[1] = kern;
+        timings_ms[2] = copy;
+    }
+    return MID_OK;
+}

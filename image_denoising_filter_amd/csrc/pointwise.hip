@@ -1,0 +1,119 @@
+// pointwise.hip -- the streaming passes: normalize (shaders/normalize.comp:29-44) and the
+// u8 <-> float conversions (src/main.cpp:97-103, :1804-1807; UNORM decode src/texture.cpp:16).
+// All three are HBM-bound: one pixel (16 B of float / 4 B of u8) per lane, grid-stride.
+#include "common.hpp"
+
+namespace mid {
+
+__global__ __launch_bounds__(256) void normalize_kernel(const mid_weightinfo *__restrict__ W,
+                                                        float4 *__restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float4 *wp = (const float4 *)(W + i);
+        const float4 wc = wp[0];
+        const float nw = wp[1].x;
+        float4 o;
+        if (nw == 0.0f) o = make_float4(1.0f, 0.0f, 1.0f, 1.0f);                 // normalize.comp:36-38
+        else o = make_float4(wc.x / nw, wc.y / nw, wc.z / nw, wc.w / nw);        // :42 (IEEE division)
+        out[i] = o;
+    }
+}
+
+template <int FLAVOUR>
+__global__ __launch_bounds__(256) void unpack_kernel(const uint32_t *__restrict__ in, float4 *__restrict__ out, size_t npix)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        const uint32_t v = in[i];
+        const float r = (float)(v & 0xffu), g = (float)((v >> 8) & 0xffu), b = (float)((v >> 16) & 0xffu), a = (float)(v >> 24);
+        if (FLAVOUR == 0) out[i] = make_float4(r / 255.0f, g / 255.0f, b / 255.0f, a / 255.0f);
+        else {
+            const float k = 1.0f / 255.0f;                                       // src/main.cpp:1804
+            out[i] = make_float4(r * k, g * k, b * k, a * k);
+        }
+    }
+}
+
+template <int FLAVOUR>
+__global__ __launch_bounds__(256) void unpack_tail_kernel(const uint8_t *in, float *out, size_t n0, size_t n)
+{
+    const size_t i = n0 + threadIdx.x;
+    if (i < n) out[i] = FLAVOUR == 0 ? (float)in[i] / 255.0f : (float)in[i] * (1.0f / 255.0f);
+}
+
+__device__ __forceinline__ uint32_t pack1(float x)
+{
+    const float v = 255.0f * x;                       // src/main.cpp:99
+    if (!(v > -1.0f)) return 0u;                      // C cast undefined (and NaN): clamp
+    if (v >= 256.0f) return 255u;
+    return (uint32_t)(int)v;                          // truncation toward zero
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const float4 *__restrict__ in, uint32_t *__restrict__ out, size_t npix)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
+        const float4 p = in[i];
+        out[i] = pack1(p.x) | (pack1(p.y) << 8) | (pack1(p.z) << 16) | (pack1(p.w) << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_tail_kernel(const float *in, uint8_t *out, size_t n0, size_t n)
+{
+    const size_t i = n0 + threadIdx.x;
+    if (i < n) out[i] = (uint8_t)pack1(in[i]);
+}
+
+static unsigned stream_grid(mid_ctx *ctx, size_t n)
+{
+    const size_t want = (n + 255) / 256, cap = (size_t)ctx->cu_count * 8;
+    return (unsigned)(want < cap ? (want ? want : 1) : cap);
+}
+
+}  // namespace mid
+
+using namespace mid;
+
+extern "C" int mid_normalize(mid_ctx *ctx, const mid_normalize_params *p, const mid_weightinfo *W,
+                             mid_pixel *out, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(p && p->width > 0 && p->height > 0, "normalize: bad params");
+    MID_REQUIRE(W && out, "normalize: NULL pointer");
+    const size_t n = (size_t)p->width * p->height;
+    hipLaunchKernelGGL(normalize_kernel, dim3(stream_grid(ctx, n)), dim3(256), 0, b.s, W, (float4 *)out, n);
+    MID_HIP(hipGetLastError());
+    return MID_OK;
+}
+
+extern "C" int mid_unpack_u8(mid_ctx *ctx, const uint8_t *in, size_t n_values, int flavour, float *out, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(in && out, "unpack_u8: NULL pointer");
+    MID_REQUIRE(flavour == 0 || flavour == 1, "unpack_u8: flavour %d is not 0 (UNORM) or 1 (CPU)", flavour);
+    MID_REQUIRE(((uintptr_t)in & 3u) == 0 && ((uintptr_t)out & 15u) == 0, "unpack_u8: in must be 4-byte and out 16-byte aligned");
+    const size_t npix = n_values / 4;
+    if (npix) {
+        if (flavour == 0) hipLaunchKernelGGL(unpack_kernel<0>, dim3(stream_grid(ctx, npix)), dim3(256), 0, b.s, (const uint32_t *)in, (float4 *)out, npix);
+        else              hipLaunchKernelGGL(unpack_kernel<1>, dim3(stream_grid(ctx, npix)), dim3(256), 0, b.s, (const uint32_t *)in, (float4 *)out, npix);
+    }
+    if (n_values & 3) {
+        if (flavour == 0) hipLaunchKernelGGL(unpack_tail_kernel<0>, dim3(1), dim3(256), 0, b.s, in, out, npix * 4, n_values);
+        else              hipLaunchKernelGGL(unpack_tail_kernel<1>, dim3(1), dim3(256), 0, b.s, in, out, npix * 4, n_values);
+    }
+    MID_HIP(hipGetLastError());
+    return MID_OK;
+}
+
+extern "C" int mid_pack_u8(mid_ctx *ctx, const float *in, size_t n_values, uint8_t *out, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(in && out, "pack_u8: NULL pointer");
+    MID_REQUIRE(((uintptr_t)out & 3u) == 0 && ((uintptr_t)in & 15u) == 0, "pack_u8: out must be 4-byte and in 16-byte aligned");
+    const size_t npix = n_values / 4;
+    if (npix) hipLaunchKernelGGL(pack_kernel, dim3(stream_grid(ctx, npix)), dim3(256), 0, b.s, (const float4 *)in, (uint32_t *)out, npix);
+    if (n_values & 3) hipLaunchKernelGGL(pack_tail_kernel, dim3(1), dim3(256), 0, b.s, in, out, npix * 4, n_values);
+    MID_HIP(hipGetLastError());
+    return MID_OK;
+}

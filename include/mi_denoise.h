@@ -1,0 +1,186 @@
+/*
+ * mi_denoise.h -- C-ABI of libmi_denoise.so, the MI355X (gfx950) denoise hot path.
+ *
+ * The reference (Reefufui/image_denoising_filter) has no library/FFI surface: its "operator
+ * interface" is the set of descriptor bindings + push-constant blocks each GLSL kernel is
+ * dispatched with, and the ComputeApplication methods that drive them.  Each entry point
+ * below names the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 (MID_OK) or a MID_ERR_* code; mid_last_error() gives the
+ *     thread-local message.  No exception crosses the ABI.  (Reference: VK_CHECK_RESULT =
+ *     print+assert, src/vk_utils.h:55-63; std::runtime_error -> EXIT_FAILURE, src/main.cpp:1987.)
+ *   - all image pointers are DEVICE pointers unless a name says host; the caller owns every
+ *     buffer (reference: the application owns every VkBuffer/VkImage, src/main.cpp:1398-1437).
+ *   - `stream` is a hipStream_t passed as void*; NULL = the context's own compute stream.
+ *     Calls are asynchronous on that stream.
+ *   - images are row-major, pixel index = width*y + x (shaders/bialteral.comp:81).
+ *   - there is NO CPU fallback: without a usable HIP device mid_ctx_create fails.
+ */
+#ifndef MI_DENOISE_H
+#define MI_DENOISE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MID_VERSION 100
+
+enum {
+    MID_OK = 0,
+    MID_ERR_INVALID = 1,      /* bad argument / illegal mode combination (reference: assert, src/main.cpp:1315-1316) */
+    MID_ERR_HIP = 2,          /* a HIP runtime call failed */
+    MID_ERR_NO_DEVICE = 3,    /* no gfx950-capable device: the product path refuses to run */
+    MID_ERR_UNSUPPORTED = 4,  /* parameter combination without a kernel */
+    MID_ERR_IO = 5            /* file decode/encode failure (codec + CLI layer) */
+};
+
+/* struct Pixel {float r,g,b,a;}  -- src/main.cpp:39-41, the shaders' `struct Pixel{vec4 value;}` */
+typedef struct mid_pixel { float r, g, b, a; } mid_pixel;
+
+/* struct WeightInfo {vec4 weightColor; float normWeight;} at std430 stride 32 B --
+ * shaders/nonlocal.comp:10-14, shaders/bialteral_layers.comp:8-12, shaders/normalize.comp:13-17;
+ * host agrees: src/main.cpp:43-46 (struct NLM), :1399 (bufferSizeWeights). */
+typedef struct mid_weightinfo {
+    float weightColor[4];
+    float normWeight;
+    float _pad[3];
+} mid_weightinfo;
+
+/* Texel format of an input image: the reference creates RGBA32F textures for .exr and
+ * RGBA8_UNORM for .png (src/texture.cpp:16, src/main.cpp:333-346). */
+enum { MID_FMT_RGBA32F = 0, MID_FMT_RGBA8 = 1 };
+
+/* Addressing of the bilateral input: bialteral.comp (sampler2D, 2-D texelFetch, out-of-image
+ * texel = 0) vs bialteral_linear.comp (samplerBuffer, flat index c + j + i*width: columns wrap
+ * into the adjacent row, index outside [0,N) = 0).  m_linear = !nonlinear, src/main.cpp:1311. */
+enum { MID_LAYOUT_TEXTURE = 0, MID_LAYOUT_LINEAR = 1 };
+
+/* Push-constant block of bialteral.comp / bialteral_linear.comp / bialteral_layers.comp
+ * (shaders/bialteral.comp:13-20: {int width; int height; float spatialSigma; float colorSigma},
+ * 16 B, pushed at src/main.cpp:801-808 and :873-877 with {2.0f, 0.2f}); the first 16 bytes are
+ * that block byte for byte.  `radius` replaces `#define TEXEL_WINDOW 20` (shaders/bialteral.comp:5). */
+typedef struct mid_bilateral_params {
+    int32_t width;
+    int32_t height;
+    float   spatialSigma;
+    float   colorSigma;
+    int32_t radius;   /* window is (2*radius+1)^2; kernels exist for 1..24 */
+    int32_t layout;   /* MID_LAYOUT_* (ignored by the layers kernels: always texture) */
+    int32_t format;   /* MID_FMT_* of `in` */
+} mid_bilateral_params;
+
+/* Push-constant block of nonlocal.comp (shaders/nonlocal.comp:16-22: {int width; int height;
+ * float filteringParameter}, 12 B, pushed at src/main.cpp:865-872 with 0.5f).  The ranges
+ * replace `#define WINDOW 7` / `#define PATCH_WINDOW 3` (shaders/nonlocal.comp:5-6) and are
+ * HALF-OPEN [lo,hi) like the shader's loops (:36-44): the reference is search [-7,7) patch
+ * [-3,3); the 21x21 / 7x7 benchmark configuration is search [-10,11) patch [-3,4). */
+typedef struct mid_nlm_params {
+    int32_t width;
+    int32_t height;
+    float   filteringParameter;
+    int32_t search_lo, search_hi;
+    int32_t patch_lo, patch_hi;
+    int32_t format;   /* MID_FMT_* of target and neighbour images */
+} mid_nlm_params;
+
+/* Push-constant block of normalize.comp (shaders/normalize.comp:19-24), 8 B. */
+typedef struct mid_normalize_params { int32_t width; int32_t height; } mid_normalize_params;
+
+typedef struct mid_ctx mid_ctx;   /* opaque; bound to one HIP device */
+
+/* ---- context / errors / memory -------------------------------------------------------
+ * Replaces the Vulkan bootstrap (src/vk_utils.cpp:13-305) and buffer factories
+ * (src/main.cpp:247-401): a context is one device + one compute stream. */
+int         mid_ctx_create(int device, mid_ctx **out);
+void        mid_ctx_destroy(mid_ctx *ctx);
+const char *mid_last_error(void);
+int         mid_version(void);
+int         mid_device_name(mid_ctx *ctx, char *buf, size_t buflen);
+
+int mid_alloc(mid_ctx *ctx, size_t bytes, void **dptr);              /* CreateWriteOnlyBuffer & co */
+int mid_free(mid_ctx *ctx, void *dptr);
+int mid_alloc_host(mid_ctx *ctx, size_t bytes, void **hptr);         /* pinned staging (CreateStagingBuffer/CreateDynamicBuffer) */
+int mid_free_host(mid_ctx *ctx, void *hptr);
+int mid_memcpy_h2d(mid_ctx *ctx, void *dst, const void *src_host, size_t bytes, void *stream);  /* LoadImageDataToBuffer + copy-to-texture, src/main.cpp:1105-1142,990-1076 */
+int mid_memcpy_d2h(mid_ctx *ctx, void *dst_host, const void *src, size_t bytes, void *stream);  /* vkCmdCopyBuffer to staging + GetImageFromGPU, src/main.cpp:835-840,91-123 */
+int mid_memset(mid_ctx *ctx, void *dst, int value, size_t bytes, void *stream);                 /* the reference never clears its weight buffer; callers of *_accum must */
+int mid_stream_sync(mid_ctx *ctx, void *stream);                     /* vkWaitForFences, src/main.cpp:1092 */
+
+/* ---- a1/a2: plain bilateral -----------------------------------------------------------
+ * Replaces the dispatch of shaders/bialteral.comp / bialteral_linear.comp recorded by
+ * RecordCommandsOfExecuteAndTransfer(normKernel=false), src/main.cpp:785-847: bindings
+ * {0: vec4 out[N]; 1: image}. */
+int mid_bilateral(mid_ctx *ctx, const mid_bilateral_params *p,
+                  const void *in, mid_pixel *out, void *stream);
+
+/* ---- a3: layer-guided bilateral ---------------------------------------------------------
+ * mid_bilateral_layers_accum = one dispatch of shaders/bialteral_layers.comp
+ * (RecordCommandsOfExecuteNLM(nlm=false), src/main.cpp:849-887): W[p] += sums, bindings
+ * {0: WeightInfo W[N]; 1: inputTex; 2: layerTex (always RGBA8, src/main.cpp:1396,1419-1420)}.
+ * mid_bilateral_layers = the whole per-layer loop src/main.cpp:1610-1623 plus normalize
+ * (:1649-1652) fused in one kernel: no WeightInfo traffic. */
+int mid_bilateral_layers_accum(mid_ctx *ctx, const mid_bilateral_params *p, const void *in,
+                               const uint32_t *layer_rgba8, mid_weightinfo *W, void *stream);
+int mid_bilateral_layers(mid_ctx *ctx, const mid_bilateral_params *p, const void *in,
+                         const uint32_t *const *layers_rgba8 /* host array of device ptrs */,
+                         int n_layers, mid_pixel *out, void *stream);
+
+/* ---- a4: non-local means ----------------------------------------------------------------
+ * mid_nlm_accum = one dispatch of shaders/nonlocal.comp (RecordCommandsOfExecuteNLM(nlm=true),
+ * src/main.cpp:849-887, loop :1577-1606): W[p] += (weightColor, 0.001 + sum of weights) for one
+ * neighbour frame, target fixed; bindings {0: W; 1: u_targetImage; 2: u_neighbourImage}.
+ * mid_nlm_temporal = the multi-frame mode (src/main.cpp:1539-1606) for an animation: for each
+ * output frame t in [first, first+count) it accumulates over neighbour frames
+ * max(0,t-k)..min(n_frames-1,t+k) in ascending order (target = frame t) and normalizes, all in
+ * one launch (grid.z = output frame); k = 0 is independent single-frame NLM over a batch. */
+int mid_nlm_accum(mid_ctx *ctx, const mid_nlm_params *p, const void *target,
+                  const void *neighbour, mid_weightinfo *W, void *stream);
+int mid_nlm_temporal(mid_ctx *ctx, const mid_nlm_params *p,
+                     const void *const *frames /* host array of n_frames device ptrs */,
+                     int n_frames, int k, int first, int count,
+                     mid_pixel *const *out /* host array of `count` device ptrs */, void *stream);
+
+/* ---- a5: normalize ----------------------------------------------------------------------
+ * One dispatch of shaders/normalize.comp (RecordCommandsOfExecuteAndTransfer(normKernel=true)):
+ * out = weightColor / normWeight, or (1,0,1,1) where normWeight == 0; bindings {0: out; 1: W}. */
+int mid_normalize(mid_ctx *ctx, const mid_normalize_params *p,
+                  const mid_weightinfo *W, mid_pixel *out, void *stream);
+
+/* ---- a6: u8 <-> float -------------------------------------------------------------------
+ * unpack flavour 0 = UNORM texel decode c/255 (src/texture.cpp:16, src/main.cpp:341);
+ *        flavour 1 = CPU decode (float)c * (1.0f/255.0f) (src/main.cpp:1804-1807).
+ * pack = (unsigned char)(255.0f*v), truncation (GetImageFromGPU, src/main.cpp:97-103), clamped
+ * to [0,255] only where that cast is undefined in C.  n_values counts channels, not pixels. */
+int mid_unpack_u8(mid_ctx *ctx, const uint8_t *in, size_t n_values, int flavour, float *out, void *stream);
+int mid_pack_u8(mid_ctx *ctx, const float *in, size_t n_values, uint8_t *out, void *stream);
+
+/* ---- a8: frame pipeline -----------------------------------------------------------------
+ * Replaces RecordCommandsOfOverlappingNLM + the ping-pong loop (src/main.cpp:889-989,
+ * :1539-1573): host frames in, host frames out.  Frame t+k+1 is uploaded (hipMemcpyAsync from
+ * pinned slots on an upload stream) while frame t is filtered on the compute stream and frame
+ * t-1 is downloaded on a third stream; a device ring keeps the 2k+2 frames in flight.
+ * host_frames/host_out are arrays of n_frames HOST pointers (RGBA32F or RGBA8 per p->format;
+ * output always RGBA32F).  Synchronous: returns when every output is on the host.
+ * timings_ms (optional, 3 floats): total wall, sum of kernel time, sum of copy time. */
+int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
+                     int n_frames, int k, mid_pixel *const *host_out, int overlap, float *timings_ms);
+
+/* ---- measurement helper -----------------------------------------------------------------
+ * Timestamps around a region on a stream (reference: vkCmdWriteTimestamp pool,
+ * src/main.cpp:747-755,793-796,812-814).  tick/tock record hipEvents on `stream`;
+ * mid_timer_ms waits for the tock and returns elapsed milliseconds. */
+typedef struct mid_timer mid_timer;
+int mid_timer_create(mid_ctx *ctx, mid_timer **out);
+int mid_timer_destroy(mid_timer *t);
+int mid_timer_tick(mid_timer *t, void *stream);
+int mid_timer_tock(mid_timer *t, void *stream);
+int mid_timer_ms(mid_timer *t, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_DENOISE_H */

@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of the denoise hot path on MI355X.
+
+Metric (BASELINE.json): Mpixel/s of non-local means, 21x21 search / 7x7 patch, on 1920x1080
+RGBA32F frames resident in HBM.  A "step" is one pass of the hot path over one batch of
+`--frames` synthetic frames per GPU (one fused launch: accumulate + normalize per frame).
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); single-frame NLM shards by
+frame with no data-path collective, so every rank filters its own batch ("weak" scaling) and
+value = all ranks' pixels / max-over-ranks time.  After the timed region (outside it) the run
+also measures, and reports under "also": bilateral r=8 in both layouts (BASELINE configs[1]), the
+temporal +-2 NLM with its RCCL halo exchange (configs[4]) and the PCIe-inclusive pipeline rate.
+
+Prints ONE JSON line (rank 0).  The oracle is used only for the cpu_baseline leg.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+NPIX = W * H
+SEARCH, PATCH = (-10, 11), (-3, 4)        # 21x21 / 7x7, half-open
+HPARAM = 0.5
+# algorithmic work per pixel: minimum-work NLM = 32 flop per (pixel, offset)
+NLM_FLOP_PER_PX = 32 * 21 * 21            # 14,112
+NLM_BYTES_PER_PX = 32                     # 16 B read + 16 B written (fused accumulate+normalize)
+BIL_FLOP_PER_PX = 20 * 17 * 17            # 5,780 at r=8
+BIL_BYTES_PER_PX = 32
+PEAK_FP32_TFLOPS = 157.3                  # MI355X_MICROARCH.md: fp32 vector = dense f32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_frames(n, seed, device):
+    """Seeded 'path-tracer-like' HDR frames: piecewise-smooth radiance with
+    highlights times per-pixel Gamma(4) noise, alpha = 1.  Generated on the GPU with torch."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                            torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
+    base = torch.stack([0.6 + 0.4 * torch.sin(xx * 0.011 + 1.0), 0.5 + 0.5 * torch.cos(yy * 0.007),
+                        0.4 + 0.3 * torch.sin((xx + yy) * 0.005)], -1)
+    hl = torch.exp(-(((xx - 0.6 * W) ** 2 + (yy - 0.3 * H) ** 2) / (0.02 * W * H)))[..., None] * 6.0
+    out = []
+    for i in range(n):
+        # Gamma(4, 1/4) as the mean of 4 exponentials; pan 2 px per frame
+        u = torch.rand((4, H, W, 1), generator=g, device=device).clamp_min(1e-7)
+        noise = (-torch.log(u)).mean(0)
+        rad = torch.roll(base + hl, shifts=2 * i, dims=1) * noise
+        out.append(torch.cat([rad, torch.ones((H, W, 1), device=device)], -1).contiguous())
+    return out
+
+
+class Timers:
+    """hipEvent pairs recorded on the launch stream (mid_timer_*), read after the final sync."""
+
+    def __init__(self, mid, ctx, n):
+        self.lib, self.ctx = mid.lib, ctx
+        self.t = []
+        for _ in range(n):
+            p = ctypes.c_void_p()
+            assert self.lib.mid_timer_create(ctx.handle, ctypes.byref(p)) == 0
+            self.t.append(p)
+
+    def tick(self, i, stream):
+        self.lib.mid_timer_tick(self.t[i], stream)
+
+    def tock(self, i, stream):
+        self.lib.mid_timer_tock(self.t[i], stream)
+
+    def ms(self):
+        out = []
+        for p in self.t:
+            v = ctypes.c_float()
+            assert self.lib.mid_timer_ms(p, ctypes.byref(v)) == 0
+            out.append(v.value)
+        return out
+
+
+def cpu_baseline():
+    """The reference's own CPU bilateral loop (oracle/_ref, src/main.cpp:1827-1864, r=10,
+    sigma 10/0.2, OpenMP over x) on this host's cores; bounded sample."""
+    import oracle
+    threads = min(8, os.cpu_count() or 1)          # the reference's own choice is 8 (src/main.cpp:1984)
+    rng = np.random.default_rng(1)
+    rows = 360                                     # a 1920x360 strip: ~1/3 frame, a few seconds of CPU work
+    img = (rng.random((rows, W, 4), dtype=np.float32) * 4).astype(np.float32)
+    kind = "reference" if oracle.have_ref() else "port"
+    fn = (lambda: oracle.ref_cpu_bilateral(img, 10, threads)) if kind == "reference" else \
+         (lambda: oracle.cpu_bilateral(img, 10, 10.0, 0.2, True, threads))
+    fn()
+    ts = []
+    t_all = time.perf_counter()
+    while len(ts) < 3 and time.perf_counter() - t_all < 25:
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[len(ts) // 2]
+    return {"value": round(rows * W / 1e6 / med, 4), "unit": "Mpixel/s", "cores": threads, "kind": kind,
+            "sample": f"reference CPU bilateral loop (r=10, sigma_s=10, sigma_c=0.2, {threads} OpenMP threads, -O2) "
+                      f"on a 1920x{rows} RGBA32F strip, median of {len(ts)} runs; the reference has no CPU NLM"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import image_denoising_filter_amd as mid
+    from image_denoising_filter_amd import sharding
+    ctx = mid.Context(local_rank)
+    stream = torch.cuda.current_stream().cuda_stream     # kernels and hipEvents go on torch's current stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    F = args.frames
+    frames = synth_frames(F, 100 + rank, device)
+    outs = [torch.empty((H, W, 4), device=device, dtype=torch.float32) for _ in range(F)]
+    fptr, optr = [f.data_ptr() for f in frames], [o.data_ptr() for o in outs]
+
+    def step():
+        ctx.nlm_temporal_dev(fptr, optr, W, H, HPARAM, SEARCH, PATCH, 0, 0, F, mid.FMT_RGBA32F, stream)
+
+    for _ in range(args.warmup):
+        step()
+    timers = Timers(mid, ctx, args.steps)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        timers.tick(i, stream)
+        step()
+        timers.tock(i, stream)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = timers.ms()
+    avg_launch_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+
+    value = world * F * args.steps * NPIX / 1e6 / elapsed
+    px_per_launch = F * NPIX
+    res = {
+        "metric": "Mpixel/s (NLM 21x21 search / 7x7 patch, 1920x1080 RGBA32F)",
+        "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "nlm_21x21_7x7_1080p_hdr (BASELINE configs[2]; single-frame NLM, fused accumulate+normalize)",
+                   "frames_per_gpu_per_step": F, "width": W, "height": H, "h": HPARAM,
+                   "parallelism": f"frame-sharded x{world}, no data-path collective"},
+        "roofline": {
+            "bound": "mfma", "achieved": round(NLM_FLOP_PER_PX * px_per_launch / avg_launch_s / 1e12, 3),
+            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(NLM_FLOP_PER_PX * px_per_launch / avg_launch_s / 1e12 / PEAK_FP32_TFLOPS, 4),
+            "traffic": None,
+            "kernel": "nlm_strip_kernel<-10,11,-3,4,...,FUSED>", "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+            "note": "compute roofline: the kernel is fp32-VALU bound and issues no MFMA; the peak is the fp32 "
+                    "vector peak, which equals the dense f32 MFMA peak on gfx950 (157.3 TFLOP/s). Algorithmic "
+                    "flops = 14,112/px (minimum-work separable NLM, SURVEY.md 8d) x px per launch.",
+            "hbm": {"achieved_GBs": round(NLM_BYTES_PER_PX * px_per_launch / avg_launch_s / 1e9, 1),
+                    "peak_GBs": PEAK_HBM_GBS,
+                    "frac": round(NLM_BYTES_PER_PX * px_per_launch / avg_launch_s / 1e9 / PEAK_HBM_GBS, 5)},
+        },
+    }
+
+    # ---- outside the timed region -------------------------------------------------------------
+    also = {}
+    if not args.no_extras:
+        def time_gpu(fn, n=10):
+            fn()
+            torch.cuda.synchronize()
+            tm = Timers(mid, ctx, 1)
+            tm.tick(0, stream)
+            for _ in range(n):
+                fn()
+            tm.tock(0, stream)
+            torch.cuda.synchronize()
+            return tm.ms()[0] / n / 1e3
+
+        for name, layout in (("bilateral_r8_linear", mid.LAYOUT_LINEAR), ("bilateral_r8_texture", mid.LAYOUT_TEXTURE)):
+            s = time_gpu(lambda: ctx.bilateral_dev(fptr[0], optr[0], W, H, 8, 2.0, 0.2, layout, mid.FMT_RGBA32F, stream))
+            also[name] = {"Mpixel/s": round(NPIX / 1e6 / s, 1), "ms": round(s * 1e3, 4),
+                          "valu_frac": round(BIL_FLOP_PER_PX * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
+                          "hbm_GBs": round(BIL_BYTES_PER_PX * NPIX / s / 1e9, 1),
+                          "hbm_frac": round(BIL_BYTES_PER_PX * NPIX / s / 1e9 / PEAK_HBM_GBS, 5)}
+        s1 = time_gpu(lambda: ctx.nlm_temporal_dev(fptr[:1], optr[:1], W, H, HPARAM, SEARCH, PATCH, 0, 0, 1, 0, stream))
+        also["nlm_single_frame_latency"] = {"ms": round(s1 * 1e3, 4), "Mpixel/s": round(NPIX / 1e6 / s1, 1)}
+
+        # temporal +-2 NLM over this rank's block, halo frames from the neighbours over RCCL
+        k = 2
+        n_seq = world * F
+        start, count = sharding.partition(n_seq, world)[rank]
+
+        def temporal_step():
+            have = sharding.exchange_halo(frames, n_seq, k)
+            sharding.temporal_nlm_block(ctx, have, n_seq, k, start, count, outs, HPARAM, SEARCH, PATCH, 0, stream)
+
+        temporal_step()
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            temporal_step()
+        torch.cuda.synchronize()
+        barrier()
+        te = (time.perf_counter() - t1) / reps
+        if world > 1:
+            t = torch.tensor([te], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            te = float(t.item())
+        also["temporal_nlm_k2"] = {"Mpixel/s_out": round(n_seq * NPIX / 1e6 / te, 1), "frames": n_seq,
+                                   "ms_per_sequence": round(te * 1e3, 3),
+                                   "halo": "RCCL isend/irecv of 2 frames per side" if world > 1 else "none (1 rank)"}
+
+        if rank == 0 and world == 1:
+            # PCIe-inclusive: pinned host frames in, host frames out, 3 streams (never `value`)
+            hf = [f.cpu().numpy() for f in frames[:6]]
+            _, (wall, kern, copy) = ctx.sequence_nlm(hf, k=0, overlap=True, search=SEARCH, patch=PATCH)
+            _, (wall0, _, _) = ctx.sequence_nlm(hf, k=0, overlap=False, search=SEARCH, patch=PATCH)
+            also["pipeline_pcie_inclusive"] = {"Mpixel/s_overlap": round(len(hf) * NPIX / 1e3 / wall, 1),
+                                               "Mpixel/s_serial": round(len(hf) * NPIX / 1e3 / wall0, 1),
+                                               "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3)}
+    res["also"] = also
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            res["cpu_baseline"] = cpu_baseline()
+        except Exception as e:  # the baseline is a reported extra; never fail the GPU measurement on it
+            res["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    elif rank == 0:
+        res["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (see module docstring: must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi_denoise.so")
+# MID_LIB_PATH: development override used for A/B builds of the same C-ABI (never a fallback)
+LIB_PATH = os.environ.get("MID_LIB_PATH") or os.path.join(_HERE, "libmi_denoise.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 #pragma unroll
                 for (int m = 0; m < DR; ++m) {
                     const float4 n = p[m * LW];
+                    asm volatile("" ::"v"(n.w));   // keep .w live: one ds_read_b128 (4 LDS clk) instead of ds_read_b96 (8)
                     const float dx = Tr[m] - n.x, dy = Tg[m] - n.y, dz = Tb[m] - n.z;
                     D[m] = dx * dx + dy * dy + dz * dz;
                     if (m >= NL && m < NL + R) c[m - NL] = n;   // centre texel Nb(p+s) of output row m-NL

@@ -1,0 +1,105 @@
+"""Frame-level data parallelism for animation sequences (BASELINE config 5).
+
+The reference is single-device (deviceId{0}, src/main.cpp:1321); this is new capability with the
+reference's multi-frame semantics: output frame t accumulates over neighbour frames t-k..t+k
+(src/main.cpp:1577-1606 with an explicit, clipped window).
+
+One process per GPU.  Rank r owns a contiguous block of frames.  Bilateral / single-frame NLM need
+nothing from other ranks (replicas).  Temporal NLM needs the k frames on either side of the block:
+ONE exchange step -- each rank sends its first k frames to rank r-1 and its last k to rank r+1
+(point-to-point over xGMI with backend "nccl" = RCCL; "gloo" in the CPU tests) -- and no other
+collective.  Sequence ends are clipped, not wrapped.
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def partition(n_frames: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous (start, count) per rank; the first n_frames % world ranks get one extra frame."""
+    if n_frames < 0 or world < 1:
+        raise ValueError("bad partition request")
+    q, r = divmod(n_frames, world)
+    out, s = [], 0
+    for i in range(world):
+        c = q + (1 if i < r else 0)
+        out.append((s, c))
+        s += c
+    return out
+
+
+def halo_plan(n_frames: int, world: int, k: int, rank: int):
+    """Which global frame indices this rank receives from / sends to which rank.
+    Returns (recv, send): lists of (peer_rank, [global frame ids]).  Handles blocks shorter than k
+    (a halo may then span several ranks) and empty blocks."""
+    parts = partition(n_frames, world)
+    owner = {}
+    for r, (s, c) in enumerate(parts):
+        for f in range(s, s + c):
+            owner[f] = r
+
+    def needs(r):
+        s, c = parts[r]
+        if c == 0:
+            return []
+        lo, hi = max(0, s - k), min(n_frames - 1, s + c - 1 + k)
+        return [f for f in range(lo, hi + 1) if not (s <= f < s + c)]
+
+    recv = {}
+    for f in needs(rank):
+        recv.setdefault(owner[f], []).append(f)
+    send = {}
+    for r in range(world):
+        if r == rank:
+            continue
+        for f in needs(r):
+            if owner[f] == rank:
+                send.setdefault(r, []).append(f)
+    return sorted(recv.items()), sorted(send.items())
+
+
+def exchange_halo(local: Sequence[torch.Tensor], n_frames: int, k: int, group=None):
+    """Returns {global frame id: tensor} for every frame this rank needs (its own block + halo).
+    `local` are this rank's frames in order.  One batch of isend/irecv; no-op for world_size 1 or k 0."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    start, count = partition(n_frames, world)[rank]
+    if len(local) != count:
+        raise ValueError(f"rank {rank} owns {count} frames, got {len(local)}")
+    have = {start + i: t for i, t in enumerate(local)}
+    if world == 1 or k == 0:
+        return have
+    recv, send = halo_plan(n_frames, world, k, rank)
+    proto = local[0] if count else None
+    ops = []
+    for peer, ids in recv:
+        for f in ids:
+            buf = torch.empty_like(proto)
+            have[f] = buf
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group=group, tag=f))
+    for peer, ids in send:
+        for f in ids:
+            ops.append(dist.P2POp(dist.isend, have[f], peer, group=group, tag=f))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return have
+
+
+def window_for_block(have, n_frames: int, k: int, start: int, count: int):
+    """Ordered frame list covering the block and its clipped halo, plus `first` = index of the
+    block's first frame inside it: the arguments mid_nlm_temporal takes."""
+    lo, hi = max(0, start - k), min(n_frames - 1, start + count - 1 + k)
+    return [have[f] for f in range(lo, hi + 1)], start - lo
+
+
+def temporal_nlm_block(ctx, have, n_frames, k, start, count, outs, hparam, search, patch, fmt=0, stream=None):
+    """Runs the temporal NLM of this rank's block on device tensors (torch CUDA tensors or anything
+    with data_ptr()); `outs` are `count` preallocated RGBA32F tensors."""
+    if count == 0:
+        return
+    frames, first = window_for_block(have, n_frames, k, start, count)
+    h, w = frames[0].shape[0], frames[0].shape[1]
+    ctx.nlm_temporal_dev([f.data_ptr() for f in frames], [o.data_ptr() for o in outs], w, h, hparam,
+                         search, patch, k, first, count, fmt, stream)

@@ -1,0 +1,34 @@
+"""GPU suite: the 3-stream frame pipeline (mid_sequence_nlm) -- overlap on/off and pinned/pageable
+sources all give the bits of the direct temporal call, which in turn matches the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import rel_err, synth_hdr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k,n", [(2, 7), (1, 3), (0, 4), (2, 2), (3, 12)])
+def test_sequence_matches_direct_call(ctx, k, n):
+    rng = np.random.default_rng(k * 10 + n)
+    h, w = 40, 75
+    base = (synth_hdr(rng, h, w) * 0.25).astype(np.float32)
+    frames = [(np.roll(base, 2 * i, axis=1) * rng.gamma(16.0, 1 / 16.0, (h, w, 1))).astype(np.float32) for i in range(n)]
+    direct = ctx.nlm_temporal(frames, k=k)
+    for overlap in (True, False):
+        for pinned in (True, False):
+            outs, (wall, kern, copy) = ctx.sequence_nlm(frames, k=k, overlap=overlap, pinned=pinned)
+            assert all(np.array_equal(a, b) for a, b in zip(outs, direct)), (overlap, pinned)
+            assert wall > 0 and kern > 0 and copy > 0
+    ref = oracle.nlm_temporal(frames, k=k)
+    assert max(rel_err(a, b) for a, b in zip(direct, ref)) < 2e-5
+
+
+def test_sequence_ldr_frames(ctx):
+    from conftest import synth_ldr
+    rng = np.random.default_rng(3)
+    frames = [synth_ldr(rng, 33, 70) for _ in range(4)]
+    outs, _ = ctx.sequence_nlm(frames, k=1)
+    ref = oracle.nlm_temporal([oracle.unpack_u8(f, 0) for f in frames], k=1)
+    assert max(rel_err(a, b) for a, b in zip(outs, ref)) < 2e-5

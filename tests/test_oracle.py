@@ -1,0 +1,159 @@
+"""CPU suite, part 1: the oracle itself.
+
+ - orc_cpu_bilateral is pinned against fixtures produced by the reference's own CPU loop
+   (tests/golden/ref_cpu_bilateral_*.npz) and, when oracle/_ref is built, against that loop live;
+ - the shader restatements are "parity unpinned" by the reference (it has no tests/fixtures and
+   its GLSL cannot run here); they are checked from a second direction (float64 NumPy
+   restatement of the formulas) and through properties the filters must satisfy.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import np_reference as npr
+import oracle
+from conftest import GOLDEN, rel_err, synth_hdr, synth_ldr
+
+W0 = lambda h, w: np.zeros((h, w, 8), np.float32)  # noqa: E731
+
+
+# ---- pinned: the reference's CPU loop ---------------------------------------------------------
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_cpu_bilateral_matches_reference_golden(name):
+    g = np.load(os.path.join(GOLDEN, f"ref_cpu_bilateral_{name}.npz"))
+    for threads in (1, 4):
+        out = oracle.cpu_bilateral(g["img"], int(g["radius"]), 10.0, 0.2, blue_bug=True, threads=threads)
+        assert np.array_equal(out, g["out"]), "oracle a7 must be bit-exact with the reference loop"
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref not built (no /root/reference on this box)")
+@pytest.mark.parametrize("shape,R", [((33, 41), 10), ((21, 25), 10), ((30, 19), 4), ((64, 64), 7)])
+def test_cpu_bilateral_matches_reference_live(shape, R):
+    rng = np.random.default_rng(R * 100 + shape[0])
+    img = rng.random((*shape, 4), dtype=np.float32) * 1.5
+    assert np.array_equal(oracle.cpu_bilateral(img, R, 10.0, 0.2, True, 2), oracle.ref_cpu_bilateral(img, R, 2))
+
+
+def test_cpu_bilateral_reference_quirks():
+    """Border stays Pixel{} = 0, alpha forced to 1, blue does not enter the range distance."""
+    rng = np.random.default_rng(3)
+    img = rng.random((40, 44, 4), dtype=np.float32)
+    R = 10
+    out = oracle.cpu_bilateral(img, R, 10.0, 0.2, True, 1)
+    assert np.all(out[:R] == 0) and np.all(out[:, :R] == 0)
+    assert np.all(out[-R + 1:] == 0) and np.all(out[:, -R + 1:] == 0)    # y,x <= dim-R inclusive
+    assert np.all(out[R:-R + 1, R:-R + 1, 3] == 1.0)
+    img2 = img.copy()
+    img2[..., 2] = rng.random((40, 44), dtype=np.float32)                # change blue only
+    out2 = oracle.cpu_bilateral(img2, R, 10.0, 0.2, True, 1)
+    assert np.array_equal(out[..., :2], out2[..., :2]), "with the blue bug, r/g output ignores blue"
+    out3 = oracle.cpu_bilateral(img2, R, 10.0, 0.2, False, 1)
+    assert not np.array_equal(out2[..., :2], out3[..., :2])
+
+
+# ---- regression fixtures of the restatement (unpinned) ------------------------------------------
+def test_shader_restatement_regression():
+    g = np.load(os.path.join(GOLDEN, "shader_restatement.npz"))
+    hdr, ldr = g["hdr"], g["ldr"]
+    h, w = hdr.shape[:2]
+    assert np.array_equal(oracle.bilateral_texture(hdr, 4, 2.0, 0.2), g["bil_tex_r4"])
+    assert np.array_equal(oracle.bilateral_linear(hdr, 4, 2.0, 0.2), g["bil_lin_r4"])
+    assert np.array_equal(oracle.bilateral_texture(oracle.unpack_u8(ldr, 0), 8, 2.0, 0.2), g["bil_tex_r8_ldr"])
+    W = oracle.bilateral_layers_accum(hdr, g["layer0"], W0(h, w), 4, 2.0, 0.2)
+    W = oracle.bilateral_layers_accum(hdr, g["layer1"], W, 4, 2.0, 0.2)
+    assert np.array_equal(W, g["layers_W"]) and np.array_equal(oracle.normalize(W), g["layers_out"])
+    Wn = oracle.nlm_accum(g["nlm_in_t"], g["nlm_in_n"], W0(h, w), 0.5, (-7, 7), (-3, 3))
+    assert np.array_equal(Wn, g["nlm_ref_W"]) and np.array_equal(oracle.normalize(Wn), g["nlm_ref_out"])
+    assert np.array_equal(oracle.nlm_accum(g["nlm_in_t"], g["nlm_in_n"], W0(h, w), 0.5, (-10, 11), (-3, 4)), g["nlm_bench_W"])
+
+
+# ---- second direction: float64 formulas -----------------------------------------------------------
+@pytest.mark.parametrize("R", [1, 4, 8])
+def test_bilateral_vs_float64(R):
+    rng = np.random.default_rng(R)
+    img = synth_hdr(rng, 23, 31, 2.0)
+    num, den = npr.bilateral_texture(img, R, 2.0, 0.2)
+    assert rel_err(oracle.bilateral_texture(img, R, 2.0, 0.2), num / den[..., None]) < 1e-5
+    assert rel_err(oracle.bilateral_linear(img, R, 2.0, 0.2), npr.bilateral_linear(img, R, 2.0, 0.2)) < 1e-5
+
+
+def test_layers_vs_float64():
+    rng = np.random.default_rng(5)
+    img, lay = synth_hdr(rng, 19, 27), synth_ldr(rng, 19, 27)
+    W = oracle.bilateral_layers_accum(img, lay, W0(19, 27), 4, 2.0, 0.2)
+    num, den = npr.bilateral_texture(img, 4, 2.0, 0.2, guide=lay.astype(np.float64) / 255.0)
+    assert rel_err(W[..., :4], num) < 1e-5 and rel_err(W[..., 4], den) < 1e-5
+
+
+@pytest.mark.parametrize("search,patch", [((-7, 7), (-3, 3)), ((-10, 11), (-3, 4)), ((-2, 3), (-1, 2))])
+def test_nlm_vs_float64(search, patch):
+    rng = np.random.default_rng(11)
+    t = (synth_hdr(rng, 17, 21) * 0.25).astype(np.float32)
+    nb = (t * rng.gamma(16.0, 1 / 16.0, (17, 21, 1))).astype(np.float32)
+    W = oracle.nlm_accum(t, nb, W0(17, 21), 0.5, search, patch)
+    num, den = npr.nlm_sums(t, nb, 0.5, search, patch)
+    assert rel_err(W[..., :4], num) < 2e-5 and rel_err(W[..., 4], den) < 2e-5
+
+
+# ---- properties ---------------------------------------------------------------------------------
+def test_constant_image_is_invariant_in_the_interior():
+    img = np.tile(np.array([0.3, 0.6, 0.9, 1.0], np.float32), (30, 34, 1))
+    R = 4
+    for f in (oracle.bilateral_texture, oracle.bilateral_linear):
+        out = f(img, R, 2.0, 0.2)
+        assert rel_err(out[R:-R, R:-R], img[R:-R, R:-R]) < 1e-6
+    corner = oracle.bilateral_texture(img, R, 2.0, 0.2)[0, 0]
+    assert np.all(corner < img[0, 0]), "zero texels outside the image darken the border (reference behaviour)"
+    W = oracle.nlm_accum(img, img, W0(30, 34), 0.5, (-2, 3), (-1, 2))
+    o = oracle.normalize(W)[8:-8, 8:-8]
+    assert rel_err(o * (25.001 / 25.0), img[8:-8, 8:-8]) < 1e-6, "0.001 bias on the norm (nonlocal.comp:32)"
+
+
+def test_texture_and_linear_agree_in_the_interior_and_differ_at_row_ends():
+    rng = np.random.default_rng(2)
+    img = synth_hdr(rng, 26, 33)
+    R = 4
+    a, b = oracle.bilateral_texture(img, R, 2.0, 0.2), oracle.bilateral_linear(img, R, 2.0, 0.2)
+    assert rel_err(a[:, R:-R], b[:, R:-R]) < 1e-6      # same taps, transposed loop order only
+    assert rel_err(a[:, :R], b[:, :R]) > 1e-3          # row wrap-around vs zero border
+
+
+def test_accumulation_is_linear_over_frames_and_layers():
+    rng = np.random.default_rng(8)
+    t = rng.random((14, 18, 4), dtype=np.float32)
+    n1, n2 = rng.random((14, 18, 4), dtype=np.float32), rng.random((14, 18, 4), dtype=np.float32)
+    z = W0(14, 18)
+    w1 = oracle.nlm_accum(t, n1, z, 0.5, (-2, 3), (-1, 2))
+    w2 = oracle.nlm_accum(t, n2, z, 0.5, (-2, 3), (-1, 2))
+    w12 = oracle.nlm_accum(t, n2, w1, 0.5, (-2, 3), (-1, 2))
+    assert np.array_equal(w12[..., :5], (w1 + w2)[..., :5]), "W += is a plain fp32 add of per-dispatch sums"
+    assert np.allclose(w12[..., 4].min(), 0.002, atol=1e-3) or w12[..., 4].min() > 0.002
+
+
+def test_normalize_sentinel_and_division():
+    W = W0(2, 3)
+    W[0, 0] = [1, 2, 3, 4, 2, 0, 0, 0]
+    W[0, 1] = [5, 5, 5, 5, 0, 0, 0, 0]          # normWeight == 0 -> magenta (normalize.comp:36-38)
+    W[1, 2] = [1, 1, 1, 1, 3, 9, 9, 9]          # padding is ignored
+    out = oracle.normalize(W)
+    assert np.array_equal(out[0, 0], np.float32([0.5, 1, 1.5, 2]))
+    assert np.array_equal(out[0, 1], np.float32([1, 0, 1, 1]))
+    assert np.array_equal(out[1, 2], np.float32([1, 1, 1, 1]) / np.float32(3))
+    assert np.array_equal(out[1, 0], np.float32([1, 0, 1, 1]))
+
+
+def test_u8_paths_exhaustive():
+    u8 = np.arange(256, dtype=np.uint8)
+    unorm, cpu = oracle.unpack_u8(u8, 0), oracle.unpack_u8(u8, 1)
+    assert np.array_equal(unorm, (u8.astype(np.float32) / np.float32(255)))
+    assert np.array_equal(cpu, u8.astype(np.float32) * (np.float32(1) / np.float32(255)))
+    assert unorm[255] == 1.0 and unorm[0] == 0.0
+    assert (unorm != cpu).sum() > 0, "the two decode flavours differ by 1 ulp for some codes"
+    # truncating pack (unsigned char)(255*v): both decode flavours survive the round trip for all
+    # 256 codes (fl(c/255)*255 rounds back to >= c), which is why the reference's PNG path is lossless
+    assert np.array_equal(oracle.pack_u8(unorm), u8) and np.array_equal(oracle.pack_u8(cpu), u8)
+    just_below = np.nextafter(unorm[1:], np.float32(0))
+    assert np.array_equal(oracle.pack_u8(just_below), u8[1:] - 1), "truncation, not rounding"
+    edge = np.float32([0.0, 1.0, 0.999999, -0.0, -0.5, -2.0, 1.5, np.nan, 254.999 / 255, 1 / 255, 0.00392])
+    assert list(oracle.pack_u8(edge)) == [0, 255, 254, 0, 0, 0, 255, 0, 254, 1, 0]

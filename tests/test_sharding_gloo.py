@@ -1,0 +1,91 @@
+"""CPU suite, part 3: the N>1 path (frame blocks + one halo exchange) with world_size 2 and 3 over
+gloo.  The exchanged windows are checked frame by frame, and the oracle run per shard on those
+windows must give the bits of the oracle run on the whole sequence (same kernel, same inputs)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from image_denoising_filter_amd import sharding
+
+
+def test_partition_and_plan():
+    assert sharding.partition(64, 8) == [(8 * i, 8) for i in range(8)]
+    assert sharding.partition(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    assert sharding.partition(2, 4) == [(0, 1), (1, 1), (2, 0), (2, 0)]
+    recv, send = sharding.halo_plan(64, 8, 2, 3)
+    assert recv == [(2, [22, 23]), (4, [32, 33])] and send == [(2, [24, 25]), (4, [30, 31])]
+    recv0, send0 = sharding.halo_plan(64, 8, 2, 0)
+    assert recv0 == [(1, [8, 9])] and send0 == [(1, [6, 7])]          # sequence ends clip, no wrap
+    # blocks shorter than k: the halo spans two ranks
+    recv, _ = sharding.halo_plan(4, 4, 2, 0)
+    assert recv == [(1, [1]), (2, [2])]
+    # every frame a rank needs is sent by exactly its owner
+    for world, n, k in ((3, 7, 2), (4, 5, 3), (2, 9, 1)):
+        for r in range(world):
+            rcv, _ = sharding.halo_plan(n, world, k, r)
+            for peer, ids in rcv:
+                _, snd = sharding.halo_plan(n, world, k, peer)
+                assert dict(snd)[r] == ids
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, k, h, w, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        rng = np.random.default_rng(123)
+        seq = [rng.random((h, w, 4), dtype=np.float32) for _ in range(n)]      # same on every rank
+        start, count = sharding.partition(n, world)[rank]
+        local = [torch.from_numpy(seq[start + i].copy()) for i in range(count)]
+        have = sharding.exchange_halo(local, n, k)
+        lo, hi = max(0, start - k), min(n - 1, start + count - 1 + k)
+        ok = count == 0 or sorted(have) == list(range(lo, hi + 1))
+        ok = ok and all(np.array_equal(have[f].numpy(), seq[f]) for f in have)
+        outs = []
+        if count:
+            frames, first = sharding.window_for_block(have, n, k, start, count)
+            outs = oracle.nlm_temporal([f.numpy() for f in frames], k=k, first=first, count=count,
+                                       search=(-2, 3), patch=(-1, 2))
+        q.put((rank, ok, start, [o.tobytes() for o in outs]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,k", [(2, 6, 2), (2, 5, 1), (3, 4, 2)])
+def test_sharded_sequence_equals_single_shard(world, n, k):
+    import oracle
+    h, w = 9, 12
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, n, k, h, w, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(123)
+    seq = [rng.random((h, w, 4), dtype=np.float32) for _ in range(n)]
+    whole = oracle.nlm_temporal(seq, k=k, search=(-2, 3), patch=(-1, 2))
+    seen = 0
+    for rank, ok, start, outs in results:
+        assert ok, f"rank {rank}: wrong halo"
+        for i, b in enumerate(outs):
+            assert b == whole[start + i].tobytes(), f"rank {rank} frame {start + i} differs from the 1-shard result"
+            seen += 1
+    assert seen == n

@@ -5,7 +5,7 @@ CSRC    := image_denoising_filter_amd/csrc
 LIB     := image_denoising_filter_amd/libmi_denoise.so
 SRCS    := $(CSRC)/capi.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/pipeline.cpp
 OBJS    := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
-HIPFLAGS := -x hip --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude
+HIPFLAGS := -x hip --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Iinclude
 
 all: $(LIB) oracle
 

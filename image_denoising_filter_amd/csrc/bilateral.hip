@@ -107,10 +107,10 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
                     const int j = m - R - k;               // row offset of this texel for output k
                     if (j < -R || j > R) continue;
                     const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
-                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                     const float wt = __builtin_amdgcn_exp2f(fmaf(d2, a.kc, sij[j < 0 ? -j : j]));
-                    acc[k].x += c.x * wt; acc[k].y += c.y * wt;
-                    acc[k].z += c.z * wt; acc[k].w += c.w * wt;
+                    acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
+                    acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
                     accw[k] += wt;
                 }
             }
@@ -171,9 +171,10 @@ __global__ __launch_bounds__(256) void bilateral_generic_kernel(const BilArgs a,
                     c = g;
                 }
                 const float dx = ctr.x - g.x, dy = ctr.y - g.y, dz = ctr.z - g.z;
-                const float d2 = dx * dx + dy * dy + dz * dz;
+                const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                 const float wt = __builtin_amdgcn_exp2f(fmaf(d2, a.kc, a.ks * (float)(i * i + j * j)));
-                acc.x += c.x * wt; acc.y += c.y * wt; acc.z += c.z * wt; acc.w += c.w * wt;
+                acc.x = fmaf(c.x, wt, acc.x); acc.y = fmaf(c.y, wt, acc.y);
+                acc.z = fmaf(c.z, wt, acc.z); acc.w = fmaf(c.w, wt, acc.w);
                 accw += wt;
             }
         tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;

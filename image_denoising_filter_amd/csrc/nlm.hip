@@ -17,6 +17,7 @@
 //
 // Out-of-image texels are vec4(0) for both images (LDS halo zero-filled).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace mid {
 
@@ -84,7 +85,9 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
     return x * q + (x < r ? x : r) + i;
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED>
+// MULTI = more than one neighbour frame per output (temporal window): only then are the
+// per-frame sums kept apart from the running totals (the reference's `+=` into WeightInfo).
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI>
 __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 {
     constexpr int SW = SHI - SLO, PW = PHI - PLO;
@@ -113,8 +116,8 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 
     const int t_out = a.first + fz;          // FUSED: output frame
     const void *target = FUSED ? a.frames.p[t_out] : a.target;
-    int f_lo = 0, f_hi = 0;
-    if (FUSED) {
+    int f_lo = FUSED ? t_out : 0, f_hi = f_lo;
+    if (FUSED && MULTI) {
         f_lo = t_out - a.k < 0 ? 0 : t_out - a.k;
         f_hi = t_out + a.k > a.n_frames - 1 ? a.n_frames - 1 : t_out + a.k;
     }
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
                     const float4 n = p[m * LW];
                     asm volatile("" ::"v"(n.w));   // keep .w live: one ds_read_b128 (4 LDS clk) instead of ds_read_b96 (8)
                     const float dx = Tr[m] - n.x, dy = Tg[m] - n.y, dz = Tb[m] - n.z;
-                    D[m] = dx * dx + dy * dy + dz * dz;
+                    D[m] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                     if (m >= NL && m < NL + R) c[m - NL] = n;   // centre texel Nb(p+s) of output row m-NL
                 }
                 float V[R];
@@ -164,17 +167,23 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
                 for (int k = 0; k < R; ++k) {
                     const float d = horizontal_box<PLO, PHI>(V[k]);
                     const float wt = __builtin_amdgcn_exp2f(d * a.kexp);   // exp(-d/h^2), nonlocal.comp:55
-                    acc[k].x += c[k].x * wt; acc[k].y += c[k].y * wt;      // :56
-                    acc[k].z += c[k].z * wt; acc[k].w += c[k].w * wt;
+                    acc[k].x = fmaf(c[k].x, wt, acc[k].x); acc[k].y = fmaf(c[k].y, wt, acc[k].y);   // :56
+                    acc[k].z = fmaf(c[k].z, wt, acc[k].z); acc[k].w = fmaf(c[k].w, wt, acc[k].w);
                     accw[k] += wt;                                         // :57
                 }
             }
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) {   // nlmData[p] += ..., nonlocal.comp:61-62
-            tot[k].x += acc[k].x; tot[k].y += acc[k].y; tot[k].z += acc[k].z; tot[k].w += acc[k].w;
-            totw[k] += accw[k];
+            if (MULTI) {
+                tot[k].x += acc[k].x; tot[k].y += acc[k].y; tot[k].z += acc[k].z; tot[k].w += acc[k].w;
+                totw[k] += accw[k];
+            } else {                    // 0 + x == x: a single frame's sums are the totals
+                tot[k] = acc[k];
+                totw[k] = accw[k];
+            }
         }
+        if (!MULTI) break;
     }
 
     if (!wave_active || lane < NL || lane > 63 - NR || gx >= w) return;
@@ -228,11 +237,12 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
                         const float4 t = fetch_texture<FMT>(target, a.w, a.h, px + i, py + j);
                         const float4 n = fetch_texture<FMT>(nb, a.w, a.h, x + i, y + j);
                         const float dx = t.x - n.x, dy = t.y - n.y, dz = t.z - n.z;
-                        d += dx * dx + dy * dy + dz * dz;
+                        d += fmaf(dz, dz, fmaf(dy, dy, dx * dx));
                     }
                 const float wt = __builtin_amdgcn_exp2f(d * a.kexp);
                 const float4 c = fetch_texture<FMT>(nb, a.w, a.h, x, y);
-                acc.x += c.x * wt; acc.y += c.y * wt; acc.z += c.z * wt; acc.w += c.w * wt;
+                acc.x = fmaf(c.x, wt, acc.x); acc.y = fmaf(c.y, wt, acc.y);
+                acc.z = fmaf(c.z, wt, acc.z); acc.w = fmaf(c.w, wt, acc.w);
                 accw += wt;
             }
         tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
@@ -253,14 +263,14 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
     }
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED>
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI>
 static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
 {
     constexpr int SW = SHI - SLO, PW = PHI - PLO;
     constexpr int VW = 64 - (PW - 1), TILE_H = NW * R;
     constexpr int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + SW - 1;
     constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
-    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED>;
+    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     static thread_local const void *configured = nullptr;   // per-thread, per-instantiation
@@ -279,10 +289,19 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
 template <int FMT, bool FUSED>
 static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s)
 {
-    if (p->search_lo == -10 && p->search_hi == 11 && p->patch_lo == -3 && p->patch_hi == 4)
-        return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED>(ctx, a, s);    // 21x21 / 7x7 (benchmark)
-    if (p->search_lo == -7 && p->search_hi == 7 && p->patch_lo == -3 && p->patch_hi == 3)
-        return launch_strip<-7, 7, -3, 3, 8, 8, FMT, FUSED>(ctx, a, s);      // nonlocal.comp:5-6 as shipped
+    const bool multi = FUSED && a.k > 0;
+    static const int variant = getenv("MID_NLM_VARIANT") ? atoi(getenv("MID_NLM_VARIANT")) : 0;   // tuning A/B only
+    if (p->search_lo == -10 && p->search_hi == 11 && p->patch_lo == -3 && p->patch_hi == 4) {   // 21x21 / 7x7 (benchmark)
+        if (multi) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, FUSED>(ctx, a, s);
+        if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false>(ctx, a, s);
+        if (variant == 2) return launch_strip<-10, 11, -3, 4, 7, 12, FMT, FUSED, false>(ctx, a, s);
+        if (variant == 3) return launch_strip<-10, 11, -3, 4, 6, 14, FMT, FUSED, false>(ctx, a, s);
+        return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, false>(ctx, a, s);
+    }
+    if (p->search_lo == -7 && p->search_hi == 7 && p->patch_lo == -3 && p->patch_hi == 3) {     // nonlocal.comp:5-6 as shipped
+        if (multi) return launch_strip<-7, 7, -3, 3, 8, 8, FMT, FUSED, FUSED>(ctx, a, s);
+        return launch_strip<-7, 7, -3, 3, 8, 8, FMT, FUSED, false>(ctx, a, s);
+    }
     dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16), FUSED ? a.count : 1);
     hipLaunchKernelGGL((nlm_generic_kernel<FMT, FUSED>), grid, dim3(256), 0, s, a,
                        p->search_lo, p->search_hi, p->patch_lo, p->patch_hi);

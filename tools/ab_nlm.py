@@ -1,0 +1,22 @@
+"""A/B of NLM tile variants in separate processes (MID_NLM_VARIANT is read once per process)."""
+import os, subprocess, sys
+code = r'''
+import sys, ctypes; sys.path.insert(0, ".")
+import torch, image_denoising_filter_amd as mid, bench
+torch.cuda.set_device(0); ctx = mid.Context(0); dev = torch.device("cuda", 0)
+F = 8
+frames = bench.synth_frames(F, 100, dev); outs = [torch.empty((bench.H, bench.W, 4), device=dev) for _ in range(F)]
+fp, op = [f.data_ptr() for f in frames], [o.data_ptr() for o in outs]
+s = torch.cuda.current_stream().cuda_stream
+def run(n, nf):
+    tm = bench.Timers(mid, ctx, 1); tm.tick(0, s)
+    for _ in range(n): ctx.nlm_temporal_dev(fp[:nf], op[:nf], bench.W, bench.H, 0.5, (-10, 11), (-3, 4), 0, 0, nf, 0, s)
+    tm.tock(0, s); torch.cuda.synchronize(); return tm.ms()[0] / n
+run(2, 8)
+for rep in range(3):
+    m8 = run(5, 8); m1 = run(10, 1)
+    print("variant", sys.argv[1], "batch8 %.3f ms %.0f Mpx/s | single %.3f ms %.0f Mpx/s" % (m8, 8*bench.NPIX/m8/1e3, m1, bench.NPIX/m1/1e3))
+'''
+for v in sys.argv[1:]:
+    env = dict(os.environ, MID_NLM_VARIANT=v)
+    subprocess.run([sys.executable, "-c", code, v], env=env, check=True)

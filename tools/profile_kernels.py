@@ -1,0 +1,34 @@
+"""Fixed launch mix for rocprofv3 (kernel-trace/stats and PMC passes).  Usage on the GPU box:
+   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python tools/profile_kernels.py
+   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES ... --output-format csv -d ... -- python tools/profile_kernels.py
+The same frames and parameters as bench.py's timed region (NLM 21x21/7x7, 8 frames per launch)."""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+import torch
+import image_denoising_filter_amd as mid
+import bench
+
+torch.cuda.set_device(0)
+ctx = mid.Context(0)
+dev = torch.device("cuda", 0)
+F = 8
+frames = bench.synth_frames(F, 100, dev)
+outs = [torch.empty((bench.H, bench.W, 4), device=dev) for _ in range(F)]
+fp, op = [f.data_ptr() for f in frames], [o.data_ptr() for o in outs]
+s = torch.cuda.current_stream().cuda_stream
+W, H = bench.W, bench.H
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+for _ in range(reps):
+    ctx.nlm_temporal_dev(fp, op, W, H, 0.5, (-10, 11), (-3, 4), 0, 0, F, 0, s)
+for _ in range(reps):
+    ctx.nlm_temporal_dev(fp, op, W, H, 0.5, (-7, 7), (-3, 3), 0, 0, F, 0, s)
+for _ in range(reps):
+    ctx.nlm_temporal_dev(fp, op, W, H, 0.5, (-10, 11), (-3, 4), 2, 2, 4, 0, s)      # temporal k=2, 4 outputs
+for lay in (0, 1):
+    for _ in range(reps):
+        ctx.bilateral_dev(fp[0], op[0], W, H, 8, 2.0, 0.2, lay, 0, s)
+for _ in range(reps):
+    ctx.bilateral_dev(fp[0], op[0], W, H, 20, 2.0, 0.2, 0, 0, s)
+torch.cuda.synchronize()
+print("done")

@@ -87,7 +87,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
 
 // MULTI = more than one neighbour frame per output (temporal window): only then are the
 // per-frame sums kept apart from the running totals (the reference's `+=` into WeightInfo).
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI>
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 {
     constexpr int SW = SHI - SLO, PW = PHI - PLO;
@@ -147,29 +147,61 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 #pragma unroll
         for (int k = 0; k < R; ++k) { acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); accw[k] = 0.001f; }  // nonlocal.comp:32-33
 
+        // One search offset: n[m] = Nb(q + s) for the lane's DR rows -> distances -> box sums -> weights.
+        auto compute = [&](const float4 (&n)[DR]) {
+            float D[DR];
+#pragma unroll
+            for (int m = 0; m < DR; ++m) {
+                const float dx = Tr[m] - n[m].x, dy = Tg[m] - n[m].y, dz = Tb[m] - n[m].z;
+                D[m] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            }
+            float V[R];
+            vertical_box<PW, R>(D, V);
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const float d = horizontal_box<PLO, PHI>(V[k]);
+                const float wt = __builtin_amdgcn_exp2f(d * a.kexp);   // exp(-d/h^2), nonlocal.comp:55
+                const float4 c = n[k + NL];                             // centre texel Nb(p+s) of output row k
+                acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);   // :56
+                acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
+                accw[k] += wt;                                         // :57
+            }
+            // The halo rows' alpha is never used; without this the compiler narrows their loads to
+            // ds_read_b96 (8 LDS cycles) instead of ds_read_b128 (4).  One empty asm at the END of the
+            // offset (tied to the last accumulator so it cannot be hoisted) keeps them formally live
+            // without putting a wait in front of the distance phase.
+            if constexpr (PW - 1 == 6)
+                asm volatile("" ::"v"(n[0].w), "v"(n[1].w), "v"(n[2].w), "v"(n[NL + R].w), "v"(n[NL + R + 1].w), "v"(n[NL + R + 2].w), "v"(accw[R - 1]));
+            else if constexpr (PW - 1 == 5)
+                asm volatile("" ::"v"(n[0].w), "v"(n[1].w), "v"(n[2].w), "v"(n[NL + R].w), "v"(n[NL + R + 1].w), "v"(accw[R - 1]));
+        };
+        auto load = [&](float4 (&n)[DR], const float4 *p) {
+#pragma unroll
+            for (int m = 0; m < DR; ++m) n[m] = p[m * LW];
+        };
+
         for (int sy = 0; sy < SW; ++sy) {
             const float4 *rowp = lds + (wv * R + sy) * LW + lane;
-            for (int sx = 0; sx < SW; ++sx) {
-                const float4 *p = rowp + sx;
-                float D[DR];
-                float4 c[R];
-#pragma unroll
-                for (int m = 0; m < DR; ++m) {
-                    const float4 n = p[m * LW];
-                    asm volatile("" ::"v"(n.w));   // keep .w live: one ds_read_b128 (4 LDS clk) instead of ds_read_b96 (8)
-                    const float dx = Tr[m] - n.x, dy = Tg[m] - n.y, dz = Tb[m] - n.z;
-                    D[m] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    if (m >= NL && m < NL + R) c[m - NL] = n;   // centre texel Nb(p+s) of output row m-NL
+            if constexpr (PIPE) {
+                // two-stage software pipeline over the search columns: the LDS reads of offset
+                // sx+1 are in flight while offset sx is being computed (two register sets A/B)
+                float4 A[DR], B[DR];
+                load(A, rowp);
+                for (int sx = 0; sx + 1 < SW; sx += 2) {
+                    load(B, rowp + sx + 1);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the arithmetic
+                    compute(A);
+                    if (sx + 2 < SW) load(A, rowp + sx + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute(B);
                 }
-                float V[R];
-                vertical_box<PW, R>(D, V);
-#pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    const float d = horizontal_box<PLO, PHI>(V[k]);
-                    const float wt = __builtin_amdgcn_exp2f(d * a.kexp);   // exp(-d/h^2), nonlocal.comp:55
-                    acc[k].x = fmaf(c[k].x, wt, acc[k].x); acc[k].y = fmaf(c[k].y, wt, acc[k].y);   // :56
-                    acc[k].z = fmaf(c[k].z, wt, acc[k].z); acc[k].w = fmaf(c[k].w, wt, acc[k].w);
-                    accw[k] += wt;                                         // :57
+                if constexpr (SW & 1) compute(A);
+            } else {
+#pragma unroll U
+                for (int sx = 0; sx < SW; ++sx) {
+                    float4 n[DR];
+                    load(n, rowp + sx);
+                    compute(n);
                 }
             }
         }
@@ -263,14 +295,14 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
     }
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI>
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool PIPE = false>
 static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
 {
     constexpr int SW = SHI - SLO, PW = PHI - PLO;
     constexpr int VW = 64 - (PW - 1), TILE_H = NW * R;
     constexpr int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + SW - 1;
     constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
-    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI>;
+    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, PIPE>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     static thread_local const void *configured = nullptr;   // per-thread, per-instantiation
@@ -289,18 +321,28 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
 template <int FMT, bool FUSED>
 static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s)
 {
+    // Tile shapes were chosen by A/B on MI355X (tools/ab_nlm.py): 4 waves x 8 rows per
+    // workgroup = 76 KB of LDS, so two workgroups share a CU and one computes while the other
+    // refills its tile; the search-column loop is unrolled 7x (21 = 3*7) / 2x (14 = 2*7).
     const bool multi = FUSED && a.k > 0;
     static const int variant = getenv("MID_NLM_VARIANT") ? atoi(getenv("MID_NLM_VARIANT")) : 0;   // tuning A/B only
     if (p->search_lo == -10 && p->search_hi == 11 && p->patch_lo == -3 && p->patch_hi == 4) {   // 21x21 / 7x7 (benchmark)
-        if (multi) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, FUSED>(ctx, a, s);
-        if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false>(ctx, a, s);
-        if (variant == 2) return launch_strip<-10, 11, -3, 4, 7, 12, FMT, FUSED, false>(ctx, a, s);
-        if (variant == 3) return launch_strip<-10, 11, -3, 4, 6, 14, FMT, FUSED, false>(ctx, a, s);
-        return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, false>(ctx, a, s);
+        if (multi) {
+            if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, FUSED, 1>(ctx, a, s);
+            if (variant == 2) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 1>(ctx, a, s);
+            return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3>(ctx, a, s);
+        }
+        if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, false, 3>(ctx, a, s);
+        if (variant == 2) return launch_strip<-10, 11, -3, 4, 7, 12, FMT, FUSED, false, 3>(ctx, a, s);
+        if (variant == 3) return launch_strip<-10, 11, -3, 4, 5, 16, FMT, FUSED, false, 3>(ctx, a, s);
+        if (variant == 4) return launch_strip<-10, 11, -3, 4, 7, 4, FMT, FUSED, false, 3>(ctx, a, s);
+        if (variant == 5) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s);
+        if (variant == 6) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 1, true>(ctx, a, s);
+        return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7>(ctx, a, s);
     }
     if (p->search_lo == -7 && p->search_hi == 7 && p->patch_lo == -3 && p->patch_hi == 3) {     // nonlocal.comp:5-6 as shipped
-        if (multi) return launch_strip<-7, 7, -3, 3, 8, 8, FMT, FUSED, FUSED>(ctx, a, s);
-        return launch_strip<-7, 7, -3, 3, 8, 8, FMT, FUSED, false>(ctx, a, s);
+        if (multi) return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, FUSED, 2>(ctx, a, s);
+        return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2>(ctx, a, s);
     }
     dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16), FUSED ? a.count : 1);
     hipLaunchKernelGGL((nlm_generic_kernel<FMT, FUSED>), grid, dim3(256), 0, s, a,

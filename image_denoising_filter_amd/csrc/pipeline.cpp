@@ -22,6 +22,7 @@
 // reproduced.
 #include "common.hpp"
 #include <chrono>
+#include <cstdlib>
 #include <vector>
 
 using namespace mid;
@@ -121,6 +122,15 @@ extern "C" int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const voi
     MID_HIP(hipStreamSynchronize(ctx->download));
     const auto wall1 = std::chrono::steady_clock::now();
 
+    if (getenv("MID_PIPE_TRACE")) {   // development aid: per-frame stream timeline relative to upload(0)
+        for (int t = 0; t < n; ++t) {
+            float u0, u1, k0, k1, e0, e1;
+            (void)hipEventElapsedTime(&u0, up0.ev[0], up0.ev[t]); (void)hipEventElapsedTime(&u1, up0.ev[0], up1.ev[t]);
+            (void)hipEventElapsedTime(&k0, up0.ev[0], c0.ev[t]);  (void)hipEventElapsedTime(&k1, up0.ev[0], c1.ev[t]);
+            (void)hipEventElapsedTime(&e0, up0.ev[0], d0.ev[t]);  (void)hipEventElapsedTime(&e1, up0.ev[0], d1.ev[t]);
+            fprintf(stderr, "frame %2d  up %.3f-%.3f  compute %.3f-%.3f  down %.3f-%.3f ms\n", t, u0, u1, k0, k1, e0, e1);
+        }
+    }
     if (timings_ms) {
         float kern = 0.f, copy = 0.f, ms = 0.f;
         for (int t = 0; t < n; ++t) {

@@ -15,7 +15,10 @@ def run(n, nf):
 run(2, 8)
 for rep in range(3):
     m8 = run(5, 8); m1 = run(10, 1)
-    print("variant", sys.argv[1], "batch8 %.3f ms %.0f Mpx/s | single %.3f ms %.0f Mpx/s" % (m8, 8*bench.NPIX/m8/1e3, m1, bench.NPIX/m1/1e3))
+    tm = bench.Timers(mid, ctx, 1); tm.tick(0, s)
+    for _ in range(3): ctx.nlm_temporal_dev(fp, op, bench.W, bench.H, 0.5, (-10, 11), (-3, 4), 2, 0, 8, 0, s)
+    tm.tock(0, s); torch.cuda.synchronize(); mt = tm.ms()[0] / 3
+    print("variant", sys.argv[1], "batch8 %.3f ms %.0f Mpx/s | single %.3f ms %.0f Mpx/s | temporal k=2 8 frames %.3f ms %.0f out-Mpx/s %.0f pair-Mpx/s" % (m8, 8*bench.NPIX/m8/1e3, m1, bench.NPIX/m1/1e3, mt, 8*bench.NPIX/mt/1e3, 34*bench.NPIX/mt/1e3))
 '''
 for v in sys.argv[1:]:
     env = dict(os.environ, MID_NLM_VARIANT=v)

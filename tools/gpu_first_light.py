@@ -2,7 +2,7 @@
 rough 1080p timings.  Development aid; the real suite is tests/ -m gpu."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 import image_denoising_filter_amd as mid
 

@@ -4,7 +4,7 @@
 The same frames and parameters as bench.py's timed region (NLM 21x21/7x7, 8 frames per launch)."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import image_denoising_filter_amd as mid
 import bench

@@ -3,22 +3,29 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := image_denoising_filter_amd/csrc
 LIB     := image_denoising_filter_amd/libmi_denoise.so
-SRCS    := $(CSRC)/capi.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/pipeline.cpp
+SRCS    := $(CSRC)/capi.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/pipeline.cpp \
+           $(CSRC)/codec/png.cpp $(CSRC)/codec/exr.cpp $(CSRC)/codec/image_capi.cpp
 OBJS    := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 HIPFLAGS := -x hip --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Iinclude
 
-all: $(LIB) oracle
+CLI     := image_denoising_filter_amd/mi_denoise
+
+all: $(LIB) $(CLI) oracle
+
+# the drop-in command-line driver (host C++ only; links the C-ABI library next to it)
+$(CLI): $(CSRC)/cli/mi_denoise.cpp include/mi_denoise.h $(LIB)
+	g++ -std=c++17 -O2 -fopenmp -Wall -o $@ $(CSRC)/cli/mi_denoise.cpp -Limage_denoising_filter_amd -lmi_denoise -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz
 
-build/%.o: $(CSRC)/% $(CSRC)/common.hpp include/mi_denoise.h
-	@mkdir -p build
+build/%.o: $(CSRC)/% $(CSRC)/common.hpp $(CSRC)/codec/image_io.hpp include/mi_denoise.h
+	@mkdir -p $(dir $@)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -rf build $(LIB); $(MAKE) -C oracle clean
+	rm -rf build $(LIB) $(CLI); $(MAKE) -C oracle clean
 .PHONY: all oracle clean

@@ -47,6 +47,12 @@ class NormalizeParams(ctypes.Structure):
     _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32)]
 
 
+class Image(ctypes.Structure):
+    """mid_image"""
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("format", ctypes.c_int32),
+                ("data", ctypes.c_void_p)]
+
+
 # every symbol include/mi_denoise.h declares, with its signature
 _P = ctypes.c_void_p
 _SIGNATURES = {
@@ -74,6 +80,11 @@ _SIGNATURES = {
     "mid_pack_u8": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, _P]),
     "mid_sequence_nlm": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), c_void_pp, ctypes.c_int, ctypes.c_int,
                                         c_void_pp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
+    "mid_nlm_multiframe": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), _P, c_void_pp, ctypes.c_int, _P, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_float)]),
+    "mid_image_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Image)]),
+    "mid_image_free": (None, [ctypes.POINTER(Image)]),
+    "mid_image_save": (ctypes.c_int, [ctypes.c_char_p, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "mid_timer_create": (ctypes.c_int, [_P, c_void_pp]),
     "mid_timer_destroy": (ctypes.c_int, [_P]),
     "mid_timer_tick": (ctypes.c_int, [_P, _P]),

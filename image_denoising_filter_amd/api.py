@@ -13,7 +13,7 @@ import ctypes
 
 import numpy as np
 
-from ._lib import BilateralParams, NlmParams, NormalizeParams, c_void_pp, lib
+from ._lib import BilateralParams, Image, NlmParams, NormalizeParams, c_void_pp, lib
 
 FMT_RGBA32F, FMT_RGBA8 = 0, 1
 LAYOUT_TEXTURE, LAYOUT_LINEAR = 0, 1
@@ -33,6 +33,28 @@ class MidError(RuntimeError):
 def _check(code, where):
     if code != 0:
         raise MidError(code, where)
+
+
+def load_image(path):
+    """LoadImages (src/main.cpp:145-229): '.exr' -> float32 (h,w,4), anything else as PNG -> uint8 (h,w,4).
+    Host-only (no GPU)."""
+    img = Image()
+    _check(lib.mid_image_load(str(path).encode(), ctypes.byref(img)), "mid_image_load")
+    try:
+        dt = np.float32 if img.format == FMT_RGBA32F else np.uint8
+        n = img.width * img.height * 4
+        arr = np.ctypeslib.as_array(ctypes.cast(img.data, ctypes.POINTER(ctypes.c_float if dt == np.float32 else ctypes.c_uint8)),
+                                    shape=(n,)).reshape(img.height, img.width, 4).copy()
+    finally:
+        lib.mid_image_free(ctypes.byref(img))
+    return arr
+
+
+def save_image(path, arr):
+    """SaveEXR(rgba,w,h,4,0) for float32, lodepng::encode for uint8 (src/main.cpp:1699,1717)."""
+    arr = _img(arr)
+    _check(lib.mid_image_save(str(path).encode(), arr.ctypes.data, arr.shape[1], arr.shape[0], _fmt_of(arr)),
+           "mid_image_save")
 
 
 class DeviceBuffer:
@@ -221,6 +243,19 @@ class Context:
         d_in, d_out = self.upload(f32), self.alloc(max(n, 16))
         _check(lib.mid_pack_u8(self.handle, d_in.ptr, n, d_out.ptr, None), "mid_pack_u8")
         return self.download(d_out, f32.shape, np.uint8)
+
+    def nlm_multiframe(self, target, frames, overlap=True, hparam=0.5, search=(-7, 7), patch=(-3, 3)):
+        """The reference's multi-frame mode: one target, neighbour frames streamed (mid_nlm_multiframe)."""
+        target = _img(target)
+        frames = [_img(f) for f in frames]
+        h, w = target.shape[:2]
+        out = np.empty((h, w, 4), np.float32)
+        prm = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], _fmt_of(target))
+        t = (ctypes.c_float * 3)()
+        tbl = (ctypes.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+        _check(lib.mid_nlm_multiframe(self.handle, ctypes.byref(prm), target.ctypes.data, tbl, len(frames),
+                                      out.ctypes.data, 1 if overlap else 0, t), "mid_nlm_multiframe")
+        return out, tuple(t)
 
     def sequence_nlm(self, frames, k=2, overlap=True, hparam=0.5, search=(-7, 7), patch=(-3, 3), pinned=True):
         """Host frames in, host frames out through the 3-stream pipeline (mid_sequence_nlm).

@@ -14,6 +14,7 @@
 // (2-D zero border vs flat index with row wrap-around), exactly the difference between
 // bialteral.comp:58-59 and bialteral_linear.comp:58.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace mid {
 
@@ -37,7 +38,7 @@ __device__ __forceinline__ unsigned xcd_remap_b(unsigned bid, unsigned nwg)
 // MODE 0: plain bilateral (range weight and colour from `in`)
 // MODE 1: layers, accumulate one layer into W      (one dispatch of bialteral_layers.comp)
 // MODE 2: layers, all layers fused + normalize     (loop src/main.cpp:1610-1623 + normalize.comp)
-template <int R, int P, int NW, int FMT, bool LINEAR, int MODE>
+template <int R, int P, int NW, int FMT, bool LINEAR, int MODE, int SB = 8>
 __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
 {
     constexpr int TILE_W = 64, TILE_H = NW * P;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
             for (int m = 0; m < MR; ++m) {
                 // keep the compiler from hoisting every row's LDS read to the top of the
                 // iteration (VGPR blow-up at large radius): rows are consumed in groups of 8
-                if (m % 8 == 0 && m > 0) __builtin_amdgcn_sched_barrier(0);
+                if (SB > 0 && m % (SB > 0 ? SB : 1) == 0 && m > 0) __builtin_amdgcn_sched_barrier(0);
                 const float4 g = gde_t[base + m * LW];
                 float4 c = g;
                 if (MODE != 0) c = img_t[base + m * LW];
@@ -195,12 +196,12 @@ __global__ __launch_bounds__(256) void bilateral_generic_kernel(const BilArgs a,
     }
 }
 
-template <int R, int P, int NW, int FMT, bool LINEAR, int MODE>
+template <int R, int P, int NW, int FMT, bool LINEAR, int MODE, int SB = 8>
 static int launch_tiled(mid_ctx *ctx, BilArgs &a, hipStream_t s)
 {
     constexpr int LW = 64 + 2 * R, LH = NW * P + 2 * R;
     constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float4) * (MODE == 0 ? 1 : 2);
-    auto kern = bilateral_kernel<R, P, NW, FMT, LINEAR, MODE>;
+    auto kern = bilateral_kernel<R, P, NW, FMT, LINEAR, MODE, SB>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "bilateral tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     static thread_local const void *configured = nullptr;
@@ -218,11 +219,15 @@ static int launch_tiled(mid_ctx *ctx, BilArgs &a, hipStream_t s)
 template <int FMT, bool LINEAR, int MODE>
 static int dispatch_radius(mid_ctx *ctx, int radius, BilArgs &a, hipStream_t s)
 {
+    // Tile shapes by A/B on MI355X (tools/ab_bil.py): the kernel is latency-sensitive, so many
+    // independent waves (P = 2 rows per lane, 8 waves per workgroup) beat deeper register blocking.
     switch (radius) {
-    case 4:  return launch_tiled<4, 4, 4, FMT, LINEAR, MODE>(ctx, a, s);    // BASELINE config 1 window
-    case 8:  return launch_tiled<8, 4, 4, FMT, LINEAR, MODE>(ctx, a, s);    // BASELINE configs 2 and 4
-    case 10: return launch_tiled<10, 4, 4, FMT, LINEAR, MODE>(ctx, a, s);   // CPU path window, src/main.cpp:1819
-    case 20: return launch_tiled<20, 4, 8, FMT, LINEAR, MODE>(ctx, a, s);   // TEXEL_WINDOW as shipped
+    case 4:  return launch_tiled<4, 2, 8, FMT, LINEAR, MODE>(ctx, a, s);    // BASELINE config 1 window
+    case 8:  return launch_tiled<8, 2, 8, FMT, LINEAR, MODE>(ctx, a, s);    // BASELINE configs 2 and 4
+    case 10: return launch_tiled<10, 2, 8, FMT, LINEAR, MODE>(ctx, a, s);   // CPU path window, src/main.cpp:1819
+    case 20:                                                                 // TEXEL_WINDOW as shipped
+        if (MODE == 0) return launch_tiled<20, 1, 16, FMT, LINEAR, MODE>(ctx, a, s);
+        return launch_tiled<20, 1, 8, FMT, LINEAR, MODE>(ctx, a, s);          // two tiles (image + guide) must fit 160 KB
     default: break;
     }
     dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16));

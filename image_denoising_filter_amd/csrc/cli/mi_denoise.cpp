@@ -1,0 +1,397 @@
+// mi_denoise -- drop-in command-line driver (replaces the reference's `vulkan_denoice`,
+// src/main.cpp:1935-1994) on top of libmi_denoise.so.
+//
+//   mi_denoise [image] [options]
+//
+// With no options it behaves like the reference: the positional argument is the target image
+// (default Animations/CornellBox/Animation01_LDR_0000.png, src/main.cpp:1945); six GPU modes and two
+// CPU runs execute in the reference's order (src/main.cpp:1952-1985), print the same banners and
+// timing lines (:1924-1933) and write output{-linear|-nonlinear}{-nlm|-bialteral}[-multiframe]
+// [-overlap][-layers].{png|exr} and output-cpu.{png|exr} into the current directory (:1677-1686,
+// :1870-1901).  Unlike the reference it does not need to be started from the repo root (kernels are
+// linked in, not loaded from shaders/*.spv).  The parameters the reference hard-codes (windows
+// shaders/*.comp:5-6, sigmas/h src/main.cpp:806,870,875,1833-1835, CPU window :1819, device :1321)
+// are options whose defaults are those values.
+//
+// There is no CPU fallback for the GPU modes: if the device is missing they fail and the exit code
+// is EXIT_FAILURE.  The two "Running on CPU" modes are the reference's own RunOnCPU feature
+// (src/main.cpp:1732-1921), implemented here as part of the driver.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/mi_denoise.h"
+
+namespace fs = std::filesystem;
+
+// console colours of the timing lines, src/main.cpp:21-23
+#define FOREGROUND_COLOR "\033[38;2;0;0;0m"
+#define BACKGROUND_COLOR "\033[48;2;0;255;0m"
+#define CLEAR_COLOR      "\033[0m"
+
+struct Pixel { float r, g, b, a; };   // src/main.cpp:39-41
+
+struct Options {
+    std::string image = "Animations/CornellBox/Animation01_LDR_0000.png";   // src/main.cpp:1945
+    std::string outdir = ".";
+    int device = 0;                 // deviceId{0}, src/main.cpp:1321
+    int radius = 20;                // TEXEL_WINDOW, shaders/bialteral.comp:5
+    float sigma_s = 2.0f, sigma_c = 0.2f;      // src/main.cpp:806,875
+    float nlm_h = 0.5f;             // src/main.cpp:870
+    int search_lo = -7, search_hi = 7, patch_lo = -3, patch_hi = 3;   // shaders/nonlocal.comp:5-6, half-open
+    int temporal_k = -1;            // <0: the reference's frame list; >=0: window t-k..t+k of the sorted sequence
+    int cpu_radius = 10;            // windowSize, src/main.cpp:1819
+    float cpu_sigma_s = 10.0f, cpu_sigma_c = 0.2f;   // src/main.cpp:1833-1835
+    bool cpu_blue_bug = true;       // pow(texColor.b - texColor.b, 2), src/main.cpp:1850
+    std::vector<int> cpu_threads = {1, 8};     // src/main.cpp:1979,1984
+    bool run_gpu = true, run_cpu = true;
+    std::string modes = "all";      // comma list of: bilateral,layers,linear,nlm,multiframe,overlap
+};
+
+#define MID_CHECK(call)                                                                          \
+    do {                                                                                         \
+        if ((call) != 0) throw std::runtime_error(std::string(#call) + ": " + mid_last_error()); \
+    } while (0)
+
+// ---- RunOnCPU, src/main.cpp:1732-1921 -----------------------------------------------------------------
+// The reference's CPU bilateral: window `radius`, double-precision pow/sqrt/exp stored to float, float
+// accumulators, rows [radius, h-radius] and columns [radius, w-radius] INCLUSIVE (the last row/column
+// read one past the image; here flat indices >= N read a zero pixel), range distance over r,g only when
+// blue_bug (the reference's typo), alpha forced to 1, untouched border = Pixel{}.
+static void cpu_bilateral_refpath(const std::vector<Pixel> &in, int w, int h, int radius, float spatialSigma,
+                                  float colorSigma, bool blue_bug, int numThreads, std::vector<Pixel> &out)
+{
+    const long n = (long)w * h;
+    out.assign((size_t)n, Pixel{0.f, 0.f, 0.f, 0.f});
+    auto fetch = [&](long idx) -> Pixel { return (idx >= 0 && idx < n) ? in[(size_t)idx] : Pixel{0.f, 0.f, 0.f, 0.f}; };
+    for (int y = radius; y <= h - radius && y < h; ++y) {
+#pragma omp parallel for default(shared) num_threads(numThreads)
+        for (int x = radius; x <= w - radius; ++x) {
+            if (x >= w) continue;
+            const Pixel texColor = in[(size_t)y * w + x];
+            float normWeight = 0.0f, wr = 0.f, wg = 0.f, wb = 0.f;
+            for (int i = -radius; i <= radius; ++i)
+                for (int j = -radius; j <= radius; ++j) {
+                    const float spatialDistance = (float)std::sqrt((double)(float)std::pow((double)i, 2.0) + std::pow((double)j, 2.0));
+                    const float spatialWeight = (float)std::exp(-0.5 * std::pow((double)(spatialDistance / spatialSigma), 2.0));
+                    const Pixel cur = fetch((long)w * (i + y) + j + x);
+                    const double db = blue_bug ? std::pow((double)(texColor.b - texColor.b), 2.0) : std::pow((double)(texColor.b - cur.b), 2.0);
+                    const float colorDistance = (float)std::sqrt(std::pow((double)(texColor.r - cur.r), 2.0) + std::pow((double)(texColor.g - cur.g), 2.0) + db);
+                    const float colorWeight = (float)std::exp(-0.5 * std::pow((double)(colorDistance / colorSigma), 2.0));
+                    const float resultWeight = spatialWeight * colorWeight;
+                    wr += cur.r * resultWeight; wg += cur.g * resultWeight; wb += cur.b * resultWeight;
+                    normWeight += resultWeight;
+                }
+            out[(size_t)y * w + x] = Pixel{wr / normWeight, wg / normWeight, wb / normWeight, 1.0f};
+        }
+    }
+}
+
+class DenoiseApplication {
+    Options opt;
+    double m_execMs = 0, m_transferMs = 0;
+
+    static bool is_hdr(const std::string &p) { return fs::path(p).extension() == ".exr"; }   // src/main.cpp:1380
+
+    struct HostImage {
+        int w = 0, h = 0, format = 0;
+        std::vector<uint8_t> bytes;
+    };
+
+    static HostImage load(const std::string &path, bool force_png)
+    {
+        // layers are always decoded as PNG (src/main.cpp:1396 passes a_isHDR=false)
+        if (force_png && is_hdr(path)) throw std::runtime_error("layer " + path + " is not a PNG");
+        mid_image img{};
+        if (int rc = mid_image_load(path.c_str(), &img)) {
+            (void)rc;
+            throw std::runtime_error(mid_last_error());        // lodepng error -> runtime_error, src/main.cpp:202
+        }
+        HostImage h;
+        h.w = img.width; h.h = img.height; h.format = img.format;
+        const size_t n = (size_t)img.width * img.height * (img.format == MID_FMT_RGBA32F ? 16 : 4);
+        h.bytes.assign((uint8_t *)img.data, (uint8_t *)img.data + n);
+        mid_image_free(&img);
+        return h;
+    }
+
+    std::string out_path(const std::string &name) const { return (fs::path(opt.outdir) / name).string(); }
+
+public:
+    explicit DenoiseApplication(const Options &o) : opt(o) {}
+    double GetTransferMs() const { return m_transferMs; }
+    double GetExecMs() const { return m_execMs; }
+
+    // Frame / layer discovery, src/main.cpp:1343-1378.  Differences, all documented in DESIGN.md:
+    // entries are sorted by name (the reference uses directory order, which is unspecified), and the
+    // 4-character frame id comes from the file name's stem (the reference's find(".") breaks on "./x").
+    void discover(std::vector<std::string> &frames, std::vector<std::string> &layers, bool want_frames, bool want_layers) const
+    {
+        const fs::path target(opt.image);
+        fs::path parent = target.parent_path();
+        if (parent.empty()) parent = ".";
+        const std::string stem = target.stem().string();
+        const std::string imageID = stem.size() >= 4 ? stem.substr(stem.size() - 4) : stem;
+        std::vector<fs::path> entries;
+        for (auto &p : fs::directory_iterator(parent)) entries.push_back(p.path());
+        std::sort(entries.begin(), entries.end());
+        for (auto &e : entries) {
+            if (fs::is_directory(e)) {
+                if (!want_layers) continue;
+                std::vector<fs::path> inner;
+                for (auto &pp : fs::directory_iterator(e)) inner.push_back(pp.path());
+                std::sort(inner.begin(), inner.end());
+                for (auto &l : inner)
+                    if (!fs::is_directory(l) && l.string().find(imageID) != std::string::npos) layers.push_back(l.string());
+            } else if (e.extension() == target.extension() && want_frames) {
+                frames.push_back(e.string());
+            }
+        }
+    }
+
+    // RunOnGPU, src/main.cpp:1307-1730
+    void RunOnGPU(bool nlmFilter, bool nonlinear, bool multiframe, bool execAndCopyOverlap, bool useLayers)
+    {
+        const bool linear = !nonlinear;                                              // :1311
+        if (!(nlmFilter || !multiframe)) throw std::runtime_error("multiframe works only with nlm");        // assert :1315
+        if (!(multiframe || !execAndCopyOverlap)) throw std::runtime_error("overlap needs multiframe");     // assert :1316
+        if (linear && (nlmFilter || useLayers)) throw std::runtime_error("nlm/layers exist for the texture path only");
+        m_execMs = m_transferMs = 0;
+        std::cout << "\tinit hip for device " << opt.device << "\n";
+        mid_ctx *ctx = nullptr;
+        MID_CHECK(mid_ctx_create(opt.device, &ctx));
+        struct CtxGuard { mid_ctx *c; ~CtxGuard() { mid_ctx_destroy(c); } } guard{ctx};
+
+        std::cout << "\tloading image data\n";
+        std::vector<std::string> frameNames, layerNames;
+        discover(frameNames, layerNames, multiframe, useLayers);
+        const bool hdr = is_hdr(opt.image);
+        HostImage target = load(opt.image, false);
+        const int w = target.w, h = target.h;
+        const size_t npix = (size_t)w * h, out_bytes = npix * sizeof(Pixel);
+        const int fmt = target.format;
+        auto check_dims = [&](const HostImage &im, const std::string &name) {
+            if (im.w != w || im.h != h || im.format != fmt) throw std::runtime_error(name + ": size/format differs from the target image");
+        };
+
+        std::vector<Pixel> result(npix);
+        mid_timer *tm = nullptr;
+        MID_CHECK(mid_timer_create(ctx, &tm));
+        struct TimerGuard { mid_timer *t; ~TimerGuard() { mid_timer_destroy(t); } } tguard{tm};
+        auto timed = [&](double &acc, auto &&fn) {
+            MID_CHECK(mid_timer_tick(tm, nullptr));
+            fn();
+            MID_CHECK(mid_timer_tock(tm, nullptr));
+            float ms = 0;
+            MID_CHECK(mid_timer_ms(tm, &ms));
+            acc += ms;
+        };
+
+        std::cout << "\tperforming computations\n";
+        if (nlmFilter && multiframe) {
+            // frame list: the reference loads the target first and then every sibling with the same
+            // extension (the target again among them), src/main.cpp:1390-1393; in overlap mode it uploads 10
+            // frames and dispatches over the first 9 (:1341,1539-1573).  --temporal-k switches to the explicit
+            // window t-k..t+k of the sorted sequence instead.
+            std::vector<std::string> list;
+            if (opt.temporal_k >= 0) {
+                auto it = std::find_if(frameNames.begin(), frameNames.end(), [&](const std::string &f) { return fs::equivalent(f, opt.image); });
+                const int t = it == frameNames.end() ? 0 : (int)(it - frameNames.begin());
+                for (int f = std::max(0, t - opt.temporal_k); f <= std::min((int)frameNames.size() - 1, t + opt.temporal_k); ++f) list.push_back(frameNames[f]);
+                if (list.empty()) list.push_back(opt.image);
+            } else {
+                list.push_back(opt.image);
+                list.insert(list.end(), frameNames.begin(), frameNames.end());
+                if (execAndCopyOverlap && list.size() > 9) list.resize(9);
+            }
+            std::vector<HostImage> frames;
+            for (auto &f : list) { frames.push_back(load(f, false)); check_dims(frames.back(), f); }
+            std::vector<const void *> ptrs;
+            for (auto &f : frames) ptrs.push_back(f.bytes.data());
+            mid_nlm_params p{w, h, opt.nlm_h, opt.search_lo, opt.search_hi, opt.patch_lo, opt.patch_hi, fmt};
+            float t[3] = {0, 0, 0};
+            MID_CHECK(mid_nlm_multiframe(ctx, &p, target.bytes.data(), ptrs.data(), (int)ptrs.size(), (mid_pixel *)result.data(),
+                                         execAndCopyOverlap ? 1 : 0, t));
+            m_execMs = t[1]; m_transferMs = t[2];
+        } else {
+            void *dIn = nullptr, *dOut = nullptr;
+            MID_CHECK(mid_alloc(ctx, target.bytes.size(), &dIn));
+            MID_CHECK(mid_alloc(ctx, out_bytes, &dOut));
+            timed(m_transferMs, [&] { MID_CHECK(mid_memcpy_h2d(ctx, dIn, target.bytes.data(), target.bytes.size(), nullptr)); });
+            if (nlmFilter) {                                                                    // single-frame NLM, :1577-1606 with one frame
+                mid_nlm_params p{w, h, opt.nlm_h, opt.search_lo, opt.search_hi, opt.patch_lo, opt.patch_hi, fmt};
+                const void *fr[1] = {dIn};
+                mid_pixel *ou[1] = {(mid_pixel *)dOut};
+                timed(m_execMs, [&] { MID_CHECK(mid_nlm_temporal(ctx, &p, fr, 1, 0, 0, 1, ou, nullptr)); });
+            } else if (useLayers) {                                                             // :1608-1623 + normalize
+                std::vector<void *> dLayers;
+                for (auto &ln : layerNames) {
+                    std::cout << "\t\tfeeding layer to texture\n";
+                    HostImage l = load(ln, true);
+                    if (l.w != w || l.h != h) throw std::runtime_error(ln + ": layer size differs from the target image");
+                    void *d = nullptr;
+                    MID_CHECK(mid_alloc(ctx, l.bytes.size(), &d));
+                    dLayers.push_back(d);
+                    timed(m_transferMs, [&] { MID_CHECK(mid_memcpy_h2d(ctx, d, l.bytes.data(), l.bytes.size(), nullptr)); });
+                }
+                mid_bilateral_params p{w, h, opt.sigma_s, opt.sigma_c, opt.radius, MID_LAYOUT_TEXTURE, fmt};
+                timed(m_execMs, [&] {
+                    MID_CHECK(mid_bilateral_layers(ctx, &p, dIn, (const uint32_t *const *)dLayers.data(), (int)dLayers.size(), (mid_pixel *)dOut, nullptr));
+                });
+                for (void *d : dLayers) mid_free(ctx, d);
+            } else {                                                                            // plain bialteral, :1654-1659
+                mid_bilateral_params p{w, h, opt.sigma_s, opt.sigma_c, opt.radius, linear ? MID_LAYOUT_LINEAR : MID_LAYOUT_TEXTURE, fmt};
+                timed(m_execMs, [&] { MID_CHECK(mid_bilateral(ctx, &p, dIn, (mid_pixel *)dOut, nullptr)); });
+            }
+            std::cout << "\tgetting image back\n";
+            timed(m_transferMs, [&] { MID_CHECK(mid_memcpy_d2h(ctx, result.data(), dOut, out_bytes, nullptr)); });
+            MID_CHECK(mid_stream_sync(ctx, nullptr));
+            mid_free(ctx, dIn); mid_free(ctx, dOut);
+        }
+
+        std::string outputFileName{"output"};                                                   // :1677-1686
+        outputFileName += linear ? "-linear" : "-nonlinear";
+        outputFileName += nlmFilter ? "-nlm" : "-bialteral";
+        outputFileName += multiframe ? "-multiframe" : "";
+        outputFileName += execAndCopyOverlap ? "-overlap" : "";
+        outputFileName += useLayers ? "-layers" : "";
+        save(outputFileName, result, w, h, hdr);
+        std::cout << "\tcleaning up\n";
+    }
+
+    void save(std::string name, const std::vector<Pixel> &px, int w, int h, bool hdr) const
+    {
+        if (hdr) {
+            name += ".exr";
+            MID_CHECK(mid_image_save(out_path(name).c_str(), px.data(), w, h, MID_FMT_RGBA32F));     // SaveEXR :1699
+        } else {
+            name += ".png";
+            std::cout << "\t\tencoding png\n";
+            std::vector<unsigned char> resultData((size_t)w * h * 4);
+            for (size_t i = 0; i < (size_t)w * h; ++i) {                                              // GetImageFromGPU :97-103
+                const float v[4] = {255.0f * px[i].r, 255.0f * px[i].g, 255.0f * px[i].b, 255.0f * px[i].a};
+                for (int c = 0; c < 4; ++c)      // truncation; clamped only where the C cast is undefined
+                    resultData[i * 4 + c] = !(v[c] > -1.0f) ? 0 : v[c] >= 256.0f ? 255 : (unsigned char)v[c];
+            }
+            MID_CHECK(mid_image_save(out_path(name).c_str(), resultData.data(), w, h, MID_FMT_RGBA8));  // lodepng::encode :1717
+        }
+    }
+
+    // RunOnCPU, src/main.cpp:1732-1921
+    void RunOnCPU(const std::string &fileName, int numThreads)
+    {
+        HostImage img = load(fileName, false);
+        const int w = img.w, h = img.h;
+        std::vector<Pixel> inputPixels((size_t)w * h);
+        if (img.format == MID_FMT_RGBA32F) {
+            std::cout << "\tloading hdr\n";
+            memcpy((void *)inputPixels.data(), img.bytes.data(), img.bytes.size());
+        } else {
+            for (size_t i = 0; i < (size_t)w * h; ++i) {                                              // :1804-1807
+                inputPixels[i].r = (float)img.bytes[4 * i + 0] * (1.0f / 255.0f);
+                inputPixels[i].g = (float)img.bytes[4 * i + 1] * (1.0f / 255.0f);
+                inputPixels[i].b = (float)img.bytes[4 * i + 2] * (1.0f / 255.0f);
+                inputPixels[i].a = (float)img.bytes[4 * i + 3] * (1.0f / 255.0f);
+            }
+        }
+        std::cout << "\tdoing computations\n";
+        std::vector<Pixel> outputPixels;
+        cpu_bilateral_refpath(inputPixels, w, h, opt.cpu_radius, opt.cpu_sigma_s, opt.cpu_sigma_c, opt.cpu_blue_bug, numThreads, outputPixels);
+        std::cout << "\tsaving image\n";
+        save("output-cpu", outputPixels, w, h, img.format == MID_FMT_RGBA32F);
+    }
+};
+
+static void usage()
+{
+    std::cout <<
+        "usage: mi_denoise [image] [options]\n"
+        "  image                     target .png or .exr (default Animations/CornellBox/Animation01_LDR_0000.png)\n"
+        "  --outdir DIR              where output-*.{png,exr} go (default .)\n"
+        "  --device N                HIP device (default 0)\n"
+        "  --modes LIST              comma list of bilateral,layers,linear,nlm,multiframe,overlap (default all, reference order)\n"
+        "  --gpu-only | --cpu-only   run only the GPU modes / only the CPU runs\n"
+        "  --radius R                bilateral window radius (default 20 = TEXEL_WINDOW)\n"
+        "  --sigma-s S --sigma-c C   bilateral sigmas (default 2.0 0.2)\n"
+        "  --nlm-h H                 NLM filtering parameter (default 0.5)\n"
+        "  --search LO,HI --patch LO,HI   half-open NLM ranges (default -7,7 and -3,3; 21x21/7x7 is -10,11 and -3,4)\n"
+        "  --temporal-k K            multiframe: frames t-K..t+K of the sorted sequence instead of the reference's list\n"
+        "  --cpu-radius R --cpu-sigma-s S --cpu-sigma-c C   CPU path (default 10 10.0 0.2)\n"
+        "  --cpu-threads A,B         thread counts of the CPU runs (default 1,8)\n"
+        "  --cpu-fix-blue            use the blue channel in the CPU range distance (the reference does not)\n";
+}
+
+static bool pair_arg(const char *s, int &a, int &b) { return sscanf(s, "%d,%d", &a, &b) == 2; }
+
+int main(int argc, char **argv)
+{
+    Options opt;
+    bool have_image = false;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { usage(); exit(EXIT_FAILURE); } return argv[++i]; };
+        if (a == "-h" || a == "--help") { usage(); return EXIT_SUCCESS; }
+        else if (a == "--outdir") opt.outdir = next();
+        else if (a == "--device") opt.device = atoi(next());
+        else if (a == "--modes") opt.modes = next();
+        else if (a == "--gpu-only") opt.run_cpu = false;
+        else if (a == "--cpu-only") opt.run_gpu = false;
+        else if (a == "--radius") opt.radius = atoi(next());
+        else if (a == "--sigma-s") opt.sigma_s = (float)atof(next());
+        else if (a == "--sigma-c") opt.sigma_c = (float)atof(next());
+        else if (a == "--nlm-h") opt.nlm_h = (float)atof(next());
+        else if (a == "--search") { if (!pair_arg(next(), opt.search_lo, opt.search_hi)) { usage(); return EXIT_FAILURE; } }
+        else if (a == "--patch") { if (!pair_arg(next(), opt.patch_lo, opt.patch_hi)) { usage(); return EXIT_FAILURE; } }
+        else if (a == "--temporal-k") opt.temporal_k = atoi(next());
+        else if (a == "--cpu-radius") opt.cpu_radius = atoi(next());
+        else if (a == "--cpu-sigma-s") opt.cpu_sigma_s = (float)atof(next());
+        else if (a == "--cpu-sigma-c") opt.cpu_sigma_c = (float)atof(next());
+        else if (a == "--cpu-fix-blue") opt.cpu_blue_bug = false;
+        else if (a == "--cpu-threads") {
+            opt.cpu_threads.clear();
+            std::string s = next();
+            size_t pos = 0;
+            while (pos < s.size()) { size_t c = s.find(',', pos); if (c == std::string::npos) c = s.size(); opt.cpu_threads.push_back(atoi(s.substr(pos, c - pos).c_str())); pos = c + 1; }
+        } else if (!a.empty() && a[0] == '-') { std::cerr << "unknown option " << a << "\n"; usage(); return EXIT_FAILURE; }
+        else if (!have_image) { opt.image = a; have_image = true; }
+        else { usage(); return EXIT_FAILURE; }
+    }
+    auto want = [&](const char *m) { return opt.modes == "all" || ("," + opt.modes + ",").find(std::string(",") + m + ",") != std::string::npos; };
+
+    try {
+        DenoiseApplication app{opt};
+        auto print_time = [&] {                                                   // PRINT_TIME, src/main.cpp:1924-1927
+            std::cout << FOREGROUND_COLOR << BACKGROUND_COLOR << "transfer time: " << (unsigned long long)(app.GetTransferMs() * 1e6) << "ns; "
+                      << "execution time: " << (unsigned long long)(app.GetExecMs() * 1e6) << "ns\n\n" << CLEAR_COLOR;
+        };
+        if (opt.run_gpu) {
+            if (want("bilateral")) { std::cout << "######\nRunning on GPU (nonlinear bialteral)\n######\n"; app.RunOnGPU(false, true, false, false, false); print_time(); }
+            if (want("layers")) { std::cout << "######\nRunning on GPU (nonlinear bialteral + layers)\n######\n"; app.RunOnGPU(false, true, false, false, true); print_time(); }
+            if (want("linear")) { std::cout << "######\nRunning on GPU (linear bialteral)\n######\n"; app.RunOnGPU(false, false, false, false, false); print_time(); }
+            if (want("nlm")) { std::cout << "######\nRunning on GPU (nonlocal)\n######\n"; app.RunOnGPU(true, true, false, false, false); print_time(); }
+            if (want("multiframe")) { std::cout << "######\nRunning on GPU (multiframe nonlocal)\n######\n"; app.RunOnGPU(true, true, true, false, false); print_time(); }
+            if (want("overlap")) { std::cout << "######\nRunning on GPU (multiframe nonlocal + overlapping)\n######\n"; app.RunOnGPU(true, true, true, true, false); print_time(); }
+        }
+        if (opt.run_cpu) {
+            for (int threads : opt.cpu_threads) {
+                const auto t0 = std::chrono::steady_clock::now();
+                std::cout << "######\nRunning on CPU (" << threads << (threads == 1 ? " thread" : " threads") << " bialteral)\n######\n";
+                app.RunOnCPU(opt.image, threads);
+                const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                std::cout << FOREGROUND_COLOR << BACKGROUND_COLOR << "Time taken: " << sec << " sec\n\n" << CLEAR_COLOR;   // PRINT_TIME2 :1929-1933
+            }
+        }
+    } catch (const std::exception &e) {                                         // src/main.cpp:1987-1991
+        printf("%s\n", e.what());
+        return EXIT_FAILURE;
+    }
+    return EXIT_SUCCESS;
+}

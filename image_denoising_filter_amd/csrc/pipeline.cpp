@@ -144,3 +144,78 @@ extern "C" int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const voi
     }
     return MID_OK;
 }
+
+
+// The reference's own multi-frame mode: target fixed, neighbours streamed (see mi_denoise.h).
+extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const void *host_target,
+                                  const void *const *host_frames, int n, mid_pixel *host_out,
+                                  int overlap, float *timings_ms)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(p && host_target && host_frames && host_out, "nlm_multiframe: NULL argument");
+    MID_REQUIRE(n >= 1 && p->width > 0 && p->height > 0, "nlm_multiframe: bad n=%d or size", n);
+    for (int i = 0; i < n; ++i) MID_REQUIRE(host_frames[i], "nlm_multiframe: frame %d is NULL", i);
+    const size_t npix = (size_t)p->width * p->height;
+    const size_t in_bytes = npix * (p->format == MID_FMT_RGBA8 ? 4 : 16), out_bytes = npix * 16;
+
+    DeviceBufs dtarget, dslot, dW, dout;
+    if (int rc = dtarget.make(1, in_bytes)) return rc;
+    if (int rc = dslot.make(n > 1 ? 2 : 1, in_bytes)) return rc;
+    if (int rc = dW.make(1, npix * sizeof(mid_weightinfo))) return rc;
+    if (int rc = dout.make(1, out_bytes)) return rc;
+    EventPool up0, up1, c0, c1, misc;
+    for (EventPool *e : {&up0, &up1, &c0, &c1})
+        if (int rc = e->make(n)) return rc;
+    if (int rc = misc.make(4)) return rc;
+
+    const auto wall0 = std::chrono::steady_clock::now();
+    // target + cleared weight buffer (the reference relies on a fresh allocation being zero)
+    MID_HIP(hipEventRecord(misc.ev[0], ctx->upload));
+    MID_HIP(hipMemcpyAsync(dtarget.p[0], host_target, in_bytes, hipMemcpyHostToDevice, ctx->upload));
+    MID_HIP(hipEventRecord(misc.ev[1], ctx->upload));
+    MID_HIP(hipMemsetAsync(dW.p[0], 0, npix * sizeof(mid_weightinfo), ctx->compute));
+    MID_HIP(hipStreamWaitEvent(ctx->compute, misc.ev[1], 0));
+
+    auto upload = [&](int f) -> int {
+        if (f >= 2) MID_HIP(hipStreamWaitEvent(ctx->upload, c1.ev[f - 2], 0));   // slot still read by dispatch f-2
+        MID_HIP(hipEventRecord(up0.ev[f], ctx->upload));
+        MID_HIP(hipMemcpyAsync(dslot.p[f & 1], host_frames[f], in_bytes, hipMemcpyHostToDevice, ctx->upload));
+        MID_HIP(hipEventRecord(up1.ev[f], ctx->upload));
+        return MID_OK;
+    };
+    if (int rc = upload(0)) return rc;
+    for (int f = 0; f < n; ++f) {
+        if (overlap && f + 1 < n) { if (int rc = upload(f + 1)) return rc; }     // rides beside dispatch f
+        MID_HIP(hipStreamWaitEvent(ctx->compute, up1.ev[f], 0));
+        MID_HIP(hipEventRecord(c0.ev[f], ctx->compute));
+        if (int rc = mid_nlm_accum(ctx, p, dtarget.p[0], dslot.p[f & 1], (mid_weightinfo *)dW.p[0], ctx->compute)) return rc;
+        MID_HIP(hipEventRecord(c1.ev[f], ctx->compute));
+        if (!overlap) {   // fence after every submit, src/main.cpp:1092
+            MID_HIP(hipStreamSynchronize(ctx->compute));
+            if (f + 1 < n) { if (int rc = upload(f + 1)) return rc; MID_HIP(hipStreamSynchronize(ctx->upload)); }
+        }
+    }
+    mid_normalize_params np{p->width, p->height};
+    if (int rc = mid_normalize(ctx, &np, (const mid_weightinfo *)dW.p[0], (mid_pixel *)dout.p[0], ctx->compute)) return rc;
+    MID_HIP(hipEventRecord(misc.ev[2], ctx->compute));
+    MID_HIP(hipMemcpyAsync(host_out, dout.p[0], out_bytes, hipMemcpyDeviceToHost, ctx->compute));
+    MID_HIP(hipEventRecord(misc.ev[3], ctx->compute));
+    MID_HIP(hipStreamSynchronize(ctx->upload));
+    MID_HIP(hipStreamSynchronize(ctx->compute));
+    const auto wall1 = std::chrono::steady_clock::now();
+    if (timings_ms) {
+        float kern = 0.f, copy = 0.f, ms = 0.f;
+        for (int f = 0; f < n; ++f) {
+            MID_HIP(hipEventElapsedTime(&ms, c0.ev[f], c1.ev[f])); kern += ms;
+            MID_HIP(hipEventElapsedTime(&ms, up0.ev[f], up1.ev[f])); copy += ms;
+        }
+        MID_HIP(hipEventElapsedTime(&ms, misc.ev[0], misc.ev[1])); copy += ms;
+        MID_HIP(hipEventElapsedTime(&ms, misc.ev[2], misc.ev[3])); copy += ms;
+        MID_HIP(hipEventElapsedTime(&ms, c1.ev[n - 1], misc.ev[2])); kern += ms;   // normalize
+        timings_ms[0] = std::chrono::duration<float, std::milli>(wall1 - wall0).count();
+        timings_ms[1] = kern;
+        timings_ms[2] = copy;
+    }
+    return MID_OK;
+}

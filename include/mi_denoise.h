@@ -169,6 +169,30 @@ int mid_pack_u8(mid_ctx *ctx, const float *in, size_t n_values, uint8_t *out, vo
 int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
                      int n_frames, int k, mid_pixel *const *host_out, int overlap, float *timings_ms);
 
+/* The reference's literal multi-frame mode (src/main.cpp:1539-1606): ONE target, its neighbour frames
+ * streamed from the host.  W = sum over frames of one nonlocal.comp dispatch each (target fixed), then
+ * normalize.  overlap != 0 replaces RecordCommandsOfOverlappingNLM (:889-989): frame i+1 is uploaded on
+ * the upload stream into the other of two device slots while frame i is being accumulated.
+ * host_frames: n_frames HOST pointers (format p->format); host_out: w*h RGBA32F on the host.
+ * timings_ms (optional, 3 floats): wall, kernel sum, copy sum. */
+int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const void *host_target,
+                       const void *const *host_frames, int n_frames, mid_pixel *host_out,
+                       int overlap, float *timings_ms);
+
+/* ---- 8f-2: image files ------------------------------------------------------------------
+ * mid_image_load = LoadImages (src/main.cpp:145-229): ".exr" -> RGBA32F (tinyexr LoadEXR: missing
+ * alpha = 1), anything else is decoded as PNG -> RGBA8 (lodepng::decode).  `data` is host memory
+ * owned by the library until mid_image_free.  mid_image_save = SaveEXR(rgba,w,h,4,0) (:1699) for
+ * MID_FMT_RGBA32F, lodepng::encode (:1717) for MID_FMT_RGBA8.  Host-only: no GPU needed. */
+typedef struct mid_image {
+    int32_t width, height;
+    int32_t format;   /* MID_FMT_* */
+    void   *data;
+} mid_image;
+int  mid_image_load(const char *path, mid_image *out);
+void mid_image_free(mid_image *img);
+int  mid_image_save(const char *path, const void *data, int32_t width, int32_t height, int32_t format);
+
 /* ---- measurement helper -----------------------------------------------------------------
  * Timestamps around a region on a stream (reference: vkCmdWriteTimestamp pool,
  * src/main.cpp:747-755,793-796,812-814).  tick/tock record hipEvents on `stream`;

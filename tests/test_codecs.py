@@ -1,0 +1,259 @@
+"""CPU suite, part 4: the PNG / EXR codecs behind mid_image_load / mid_image_save.
+
+The reference decodes with lodepng and tinyexr (un-vendored submodules, absent here), so there are
+no reference fixtures; PNG is cross-checked against an independent implementation that IS in this
+image (Pillow), in both directions and over every colour type / bit depth / interlace mode; EXR
+(no second implementation available) is checked by round trips, by hand-built files that exercise
+each compression / pixel type the reader accepts, and by byte-level checks of the header."""
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import image_denoising_filter_amd as mid
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+def test_png_roundtrip_and_pillow_reads_ours(tmp_path):
+    rng = np.random.default_rng(0)
+    for shape in ((1, 1), (7, 13), (64, 64), (33, 200)):
+        a = rng.integers(0, 256, (*shape, 4), dtype=np.uint8)
+        p = tmp_path / f"a_{shape[0]}x{shape[1]}.png"
+        mid.save_image(p, a)
+        assert np.array_equal(mid.load_image(p), a)
+        assert np.array_equal(np.asarray(PIL.open(p).convert("RGBA")), a)
+
+
+@pytest.mark.parametrize("mode", ["RGBA", "RGB", "L", "LA", "P", "1", "I;16"])
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_we_read_pillow_files(tmp_path, mode, interlace):
+    rng = np.random.default_rng(1)
+    h, w = 19, 23
+    if mode == "I;16":
+        im = PIL.fromarray(rng.integers(0, 65536, (h, w), dtype=np.uint16))
+        expect = np.asarray(im, dtype=np.uint16) >> 8                       # lodepng keeps the most significant byte
+        expect = np.stack([expect] * 3 + [np.full((h, w), 255)], -1).astype(np.uint8)
+    else:
+        im = PIL.fromarray(rng.integers(0, 256, (h, w, 4), dtype=np.uint8), "RGBA").convert(mode)
+        expect = np.asarray(im.convert("RGBA"))
+    p = tmp_path / "x.png"
+    if interlace:
+        # Pillow cannot write Adam7; build the interlaced stream by hand from the raw rows
+        raw = _png_rows(im)
+        _write_png(p, im, raw, interlace=True)
+        if mode == "P":
+            expect = expect.copy()
+            expect[..., 3] = 255                               # the hand-built file carries no tRNS chunk
+    else:
+        im.save(p, optimize=(mode == "P"))
+    assert np.array_equal(mid.load_image(p), expect)
+
+
+def _png_rows(im):
+    """(colour type, bit depth, bytes per pixel or bits, rows as bytes per pixel list)"""
+    mode = im.mode
+    arr = np.asarray(im)
+    if mode == "1":
+        return 0, 1, (arr.astype(np.uint8))
+    if mode == "I;16":
+        return 0, 16, arr.astype(">u2")
+    return {"L": 0, "RGB": 2, "P": 3, "LA": 4, "RGBA": 6}[mode], 8, arr
+
+
+def _write_png(path, im, raw, interlace):
+    ctype, depth, arr = raw
+    h, w = arr.shape[:2]
+
+    def pack_rows(sub):
+        out = b""
+        for row in sub:
+            if depth == 1:
+                bits = np.packbits(row.astype(np.uint8))
+                out += b"\0" + bits.tobytes()
+            else:
+                out += b"\0" + np.ascontiguousarray(row).tobytes()
+        return out
+    data = b""
+    if interlace:
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = arr[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                data += pack_rows(sub)
+    else:
+        data = pack_rows(arr)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    if ctype == 3:
+        pal = im.getpalette()
+        out += chunk(b"PLTE", bytes(pal[:768]))
+    out += chunk(b"IDAT", zlib.compress(data)) + chunk(b"IEND", b"")
+    open(path, "wb").write(out)
+
+
+def test_png_palette_transparency_and_filters(tmp_path):
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, (31, 37, 4), dtype=np.uint8)
+    im = PIL.fromarray(a, "RGBA")
+    # Pillow picks per-row filters with compress_level > 0: all five filter types get exercised
+    p = tmp_path / "f.png"
+    im.save(p, compress_level=9)
+    assert np.array_equal(mid.load_image(p), a)
+    # palette + tRNS
+    pim = im.convert("P", palette=PIL.ADAPTIVE, colors=17)
+    pim.info["transparency"] = bytes([0, 128, 255] + [255] * 14)
+    p2 = tmp_path / "p.png"
+    pim.save(p2, transparency=bytes([0, 128, 255] + [255] * 14))
+    assert np.array_equal(mid.load_image(p2), np.asarray(PIL.open(p2).convert("RGBA")))
+
+
+def test_png_errors(tmp_path):
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"not a png at all")
+    with pytest.raises(mid.MidError) as e:
+        mid.load_image(bad)
+    assert e.value.code == 5
+    with pytest.raises(mid.MidError):
+        mid.load_image(tmp_path / "missing.png")
+    good = tmp_path / "g.png"
+    mid.save_image(good, np.zeros((4, 4, 4), np.uint8))
+    blob = bytearray(good.read_bytes())
+    blob[40] ^= 0xff                                        # corrupt IDAT -> CRC mismatch
+    bad.write_bytes(bytes(blob))
+    with pytest.raises(mid.MidError):
+        mid.load_image(bad)
+
+
+# ---- EXR ------------------------------------------------------------------------------------------
+def _exr(w, h, channels, compression, lines, pixel_bytes, data_window=None, line_order=0):
+    """Hand-built scanline EXR: channels = [(name, type)], lines[y] = {name: bytes}."""
+    dw = data_window or (0, 0, w - 1, h - 1)
+
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(val)) + val
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", t, 0, 0, 0, 0, 1, 1) for n, t in channels) + b"\0"
+    hdr = struct.pack("<ii", 20000630, 2)
+    hdr += attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
+    hdr += attr("dataWindow", "box2i", struct.pack("<4i", *dw)) + attr("displayWindow", "box2i", struct.pack("<4i", *dw))
+    hdr += attr("lineOrder", "lineOrder", bytes([line_order])) + attr("pixelAspectRatio", "float", struct.pack("<f", 1))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1))
+    hdr += b"\0"
+    lpb = 16 if compression == 3 else 1
+    blocks = []
+    for y0 in range(0, h, lpb):
+        raw = b"".join(lines[y][n] for y in range(y0, min(h, y0 + lpb)) for n, _ in channels)
+        if compression in (2, 3):
+            t = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]])
+            d = t.astype(np.int16)
+            d[1:] = (d[1:] - d[:-1] + 128) & 255
+            z = zlib.compress(d.astype(np.uint8).tobytes())
+            payload = z if len(z) < len(raw) else raw
+        elif compression == 1:
+            t = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]])
+            d = t.astype(np.int16)
+            d[1:] = (d[1:] - d[:-1] + 128) & 255
+            d = d.astype(np.uint8).tobytes()
+            payload = b"".join(bytes([256 - 1 & 0xff]) + d[i:i + 1] for i in range(len(d)))   # all literals (count -1)
+            if len(payload) >= len(raw):
+                payload = raw
+        else:
+            payload = raw
+        blocks.append((dw[1] + y0, payload))
+    if line_order == 1:
+        order = list(reversed(range(len(blocks))))
+    else:
+        order = list(range(len(blocks)))
+    table_at = len(hdr)
+    pos = table_at + 8 * len(blocks)
+    offsets = [0] * len(blocks)
+    body = b""
+    for i in order:
+        offsets[i] = pos + len(body)
+        y, payload = blocks[i]
+        body += struct.pack("<ii", y, len(payload)) + payload
+    return hdr + b"".join(struct.pack("<Q", o) for o in offsets) + body
+
+
+@pytest.mark.parametrize("compression", [0, 1, 2, 3])
+@pytest.mark.parametrize("ptype", [1, 2])
+def test_exr_reader_handbuilt(tmp_path, compression, ptype):
+    rng = np.random.default_rng(compression * 3 + ptype)
+    h, w = 37, 21
+    px = (rng.random((h, w, 4)) * 4).astype(np.float16 if ptype == 1 else np.float32)
+    chans = [("A", ptype), ("B", ptype), ("G", ptype), ("R", ptype)]
+    idx = {"R": 0, "G": 1, "B": 2, "A": 3}
+    lines = [{n: np.ascontiguousarray(px[y, :, idx[n]]).tobytes() for n, _ in chans} for y in range(h)]
+    p = tmp_path / "t.exr"
+    p.write_bytes(_exr(w, h, chans, compression, lines, None, data_window=(5, -3, 5 + w - 1, -3 + h - 1),
+                       line_order=compression % 2))
+    got = mid.load_image(p)
+    assert got.dtype == np.float32 and got.shape == (h, w, 4)
+    assert np.array_equal(got, px.astype(np.float32))
+
+
+def test_exr_missing_alpha_gray_and_uint(tmp_path):
+    h, w = 5, 9
+    rng = np.random.default_rng(9)
+    rgb = rng.random((h, w, 3)).astype(np.float32)
+    chans = [("B", 2), ("G", 2), ("R", 2)]
+    lines = [{"R": rgb[y, :, 0].tobytes(), "G": rgb[y, :, 1].tobytes(), "B": rgb[y, :, 2].tobytes()} for y in range(h)]
+    p = tmp_path / "rgb.exr"
+    p.write_bytes(_exr(w, h, chans, 2, lines, None))
+    got = mid.load_image(p)
+    assert np.array_equal(got[..., :3], rgb) and np.all(got[..., 3] == 1.0)       # alpha defaults to 1 (README.md:59)
+    y_ = rng.integers(0, 1000, (h, w)).astype(np.uint32)
+    p2 = tmp_path / "y.exr"
+    p2.write_bytes(_exr(w, h, [("Y", 0)], 0, [{"Y": y_[r].tobytes()} for r in range(h)], None))
+    g = mid.load_image(p2)
+    assert np.array_equal(g[..., 0], y_.astype(np.float32)) and np.array_equal(g[..., 0], g[..., 2])
+    # half special values
+    hv = np.array([0x0000, 0x8000, 0x0001, 0x03ff, 0x0400, 0x7bff, 0x7c00, 0xfc00, 0x3c00], np.uint16)
+    p3 = tmp_path / "h.exr"
+    p3.write_bytes(_exr(9, 1, [("Y", 1)], 0, [{"Y": hv.tobytes()}], None))
+    assert np.array_equal(mid.load_image(p3)[0, :, 0], hv.view(np.float16).astype(np.float32))
+
+
+def test_exr_write_roundtrip_and_header(tmp_path):
+    rng = np.random.default_rng(4)
+    for shape in ((3, 5), (16, 16), (40, 33), (17, 64)):
+        a = (rng.standard_normal((*shape, 4)) * 3).astype(np.float32)
+        a[0, 0] = [np.inf, -0.0, 1e-42, 65504.0]
+        p = tmp_path / f"r{shape[0]}.exr"
+        mid.save_image(p, a)
+        b = mid.load_image(p)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "float EXR round trip must be bit-exact"
+        blob = p.read_bytes()
+        assert struct.unpack("<ii", blob[:8]) == (20000630, 2)
+        assert blob[8:17] == b"channels\0"
+        names = [n for n in (b"A\0", b"B\0", b"G\0", b"R\0")]
+        pos = blob.index(b"chlist\0") + 7 + 4
+        for n in names:                                       # A,B,G,R as FLOAT, like SaveEXR(...,4,0)
+            assert blob[pos:pos + 2] == n and struct.unpack("<i", blob[pos + 2:pos + 6])[0] == 2
+            pos += 2 + 16
+        comp = blob[blob.index(b"compression\0compression\0") + 24 + 4]
+        assert comp == (0 if shape[0] < 16 and shape[1] < 16 else 3)
+
+
+def test_exr_unsupported_features_are_named(tmp_path):
+    a = np.zeros((4, 4, 4), np.float32)
+    p = tmp_path / "a.exr"
+    mid.save_image(p, a)
+    blob = bytearray(p.read_bytes())
+    i = blob.index(b"compression\0compression\0") + 24 + 4
+    blob[i] = 4                                               # PIZ
+    (tmp_path / "piz.exr").write_bytes(bytes(blob))
+    with pytest.raises(mid.MidError) as e:
+        mid.load_image(tmp_path / "piz.exr")
+    assert "PIZ" in str(e.value) and e.value.code == 5
+    blob2 = bytearray(p.read_bytes())
+    blob2[5] |= 0x02                                          # tiled bit
+    (tmp_path / "tiled.exr").write_bytes(bytes(blob2))
+    with pytest.raises(mid.MidError) as e:
+        mid.load_image(tmp_path / "tiled.exr")
+    assert "tiled" in str(e.value)

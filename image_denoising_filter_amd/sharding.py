@@ -87,6 +87,67 @@ def exchange_halo(local: Sequence[torch.Tensor], n_frames: int, k: int, group=No
     return have
 
 
+def start_halo_exchange(local: Sequence[torch.Tensor], n_frames: int, k: int, group=None):
+    """Non-blocking form of exchange_halo: posts the isend/irecv batch and returns (have, requests).
+    `have` already contains this rank's own frames; halo entries are valid only after every request
+    in `requests` has been waited for."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    start, count = partition(n_frames, world)[rank]
+    if len(local) != count:
+        raise ValueError(f"rank {rank} owns {count} frames, got {len(local)}")
+    have = {start + i: t for i, t in enumerate(local)}
+    if world == 1 or k == 0 or count == 0:
+        if world > 1 and k > 0:      # an empty block still has to serve nobody and receive nothing
+            pass
+        return have, []
+    recv, send = halo_plan(n_frames, world, k, rank)
+    ops = []
+    for peer, ids in recv:
+        for f in ids:
+            buf = torch.empty_like(local[0])
+            have[f] = buf
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group=group, tag=f))
+    for peer, ids in send:
+        for f in ids:
+            ops.append(dist.P2POp(dist.isend, have[f], peer, group=group, tag=f))
+    return have, (dist.batch_isend_irecv(ops) if ops else [])
+
+
+def temporal_block_overlapped(launch, local: Sequence[torch.Tensor], n_frames: int, k: int, group=None):
+    """Temporal NLM of this rank's block with the halo exchange hidden behind the interior frames.
+
+    `launch(frames, first, count, out_offset)` filters outputs [first, first+count) of the ordered
+    frame list `frames` (what mid_nlm_temporal takes) and stores them at block-relative position
+    out_offset.  Order of events: post the halo transfers -> launch the interior outputs (their
+    windows lie inside the block, no halo needed) -> wait for the transfers -> launch the <= 2k
+    boundary outputs.  Returns the `have` dict (frames by global id)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    start, count = partition(n_frames, world)[rank]
+    have, reqs = start_halo_exchange(local, n_frames, k, group)
+    if count == 0:
+        return have
+    # outputs whose window t-k..t+k (clipped at the sequence ends) stays inside [start, start+count)
+    lo_int = start if start == 0 else start + k
+    hi_int = start + count if start + count == n_frames else start + count - k      # exclusive
+    if hi_int > lo_int:
+        own = [have[f] for f in range(start, start + count)]
+        if start == 0 and start + count == n_frames:
+            launch(own, 0, count, 0)
+        else:
+            # restrict the table so that clipping at the block edge never replaces a missing halo frame
+            w_lo, w_hi = max(start, lo_int - k), min(start + count - 1, hi_int - 1 + k)
+            launch([have[f] for f in range(w_lo, w_hi + 1)], lo_int - w_lo, hi_int - lo_int, lo_int - start)
+    for r in reqs:
+        r.wait()
+    for a, b in ((start, min(lo_int, start + count)), (max(hi_int, lo_int), start + count)):
+        if b > a:
+            w_lo, w_hi = max(0, a - k), min(n_frames - 1, b - 1 + k)
+            launch([have[f] for f in range(w_lo, w_hi + 1)], a - w_lo, b - a, a - start)
+    return have
+
+
 def window_for_block(have, n_frames: int, k: int, start: int, count: int):
     """Ordered frame list covering the block and its clipped halo, plus `first` = index of the
     block's first frame inside it: the arguments mid_nlm_temporal takes."""

@@ -222,3 +222,36 @@ def test_invalid_arguments_are_errors_not_crashes(ctx):
     d = ctx.upload(img)                                                          # src/main.cpp:1406-1428
     assert mid.lib.mid_bilateral_layers_accum(ctx.handle, ctypes.byref(p), d.ptr, d.ptr, d.ptr, None) == 1
     assert mid.lib.mid_bilateral(ctx.handle, ctypes.byref(p), d.ptr, d.ptr, None) == 1   # in-place
+
+
+# ---- sizes beyond one kernarg frame table / beyond 1080p ------------------------------------------
+def test_nlm_temporal_chunks_long_sequences(ctx):
+    """More than 96 frames: mid_nlm_temporal splits the outputs into chunks that carry their own halo."""
+    rng = np.random.default_rng(60)
+    frames = [rng.random((6, 9, 4), dtype=np.float32) for _ in range(110)]
+    got = ctx.nlm_temporal(frames, k=2, search=(-2, 3), patch=(-1, 2))
+    ref = oracle.nlm_temporal(frames, k=2, search=(-2, 3), patch=(-1, 2))
+    assert max(rel_err(a, b) for a, b in zip(got, ref)) < NLM_TOL
+    got_b = ctx.nlm_temporal(frames, k=2, **NLM_CFGS["bench"])
+    for t in (0, 1, 46, 47, 48, 93, 94, 95, 109):               # around the chunk seams (92 outputs per launch at k=2)
+        W = Z(6, 9)
+        for f in range(max(0, t - 2), min(109, t + 2) + 1):
+            W = ctx.nlm_accum(frames[t], frames[f], W, 0.5, **NLM_CFGS["bench"])
+        assert np.array_equal(got_b[t], ctx.normalize(W)), t
+
+
+def test_4k_frame_windows(ctx):
+    """3840x2160: index arithmetic beyond 1080p; oracle on windows around the far corner and a seam."""
+    rng = np.random.default_rng(61)
+    H4, W4 = 2160, 3840
+    img = (rng.random((H4, W4, 4), dtype=np.float32) * 2).astype(np.float32)
+    out_b = ctx.bilateral(img, 8, 2.0, 0.2, "texture")
+    out_n = ctx.nlm_temporal([img], k=0, **NLM_CFGS["ref"])[0]
+    for y0, x0 in ((H4 - 20, W4 - 20), (1000, 3700), (2100, 0)):
+        for out, halo, fn in ((out_b, 8, lambda c: oracle.bilateral_texture(c, 8, 2.0, 0.2)),
+                              (out_n, 10, lambda c: oracle.normalize(oracle.nlm_accum(c, c, Z(*c.shape[:2]), 0.5)))):
+            ya, yb, xa, xb = y0 - halo, y0 + 20 + halo, x0 - halo, x0 + 20 + halo
+            c = np.zeros((yb - ya, xb - xa, 4), np.float32)
+            sy, sx = slice(max(ya, 0), min(yb, H4)), slice(max(xa, 0), min(xb, W4))
+            c[sy.start - ya:sy.stop - ya, sx.start - xa:sx.stop - xa] = img[sy, sx]
+            assert rel_err(out[y0:y0 + 20, x0:x0 + 20], fn(c)[halo:halo + 20, halo:halo + 20]) < NLM_TOL, (y0, x0)

@@ -59,13 +59,26 @@ def _worker(rank, world, port, n, k, h, w, q):
             frames, first = sharding.window_for_block(have, n, k, start, count)
             outs = oracle.nlm_temporal([f.numpy() for f in frames], k=k, first=first, count=count,
                                        search=(-2, 3), patch=(-1, 2))
+        # the overlapped form (interior first, boundary after the halo has landed) must give the same bits
+        if count:
+            res = [None] * count
+
+            def launch(frames, first, cnt, off):
+                o = oracle.nlm_temporal([f.numpy() for f in frames], k=k, first=first, count=cnt, search=(-2, 3), patch=(-1, 2))
+                for i in range(cnt):
+                    assert res[off + i] is None, "an output frame was launched twice"
+                    res[off + i] = o[i]
+            sharding.temporal_block_overlapped(launch, local, n, k)
+            ok = ok and all(r is not None for r in res) and all(np.array_equal(a, b) for a, b in zip(res, outs))
+        else:
+            sharding.temporal_block_overlapped(lambda *a: None, local, n, k)
         q.put((rank, ok, start, [o.tobytes() for o in outs]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,k", [(2, 6, 2), (2, 5, 1), (3, 4, 2)])
+@pytest.mark.parametrize("world,n,k", [(2, 6, 2), (2, 5, 1), (3, 4, 2), (2, 12, 2), (3, 13, 1)])
 def test_sharded_sequence_equals_single_shard(world, n, k):
     import oracle
     h, w = 9, 12

@@ -146,7 +146,95 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
     }
 }
 
-// Any radius without a tuned instantiation: one thread per pixel, global fetches.
+// Any radius without a tuned instantiation: the same LDS-tiled scheme with the radius as a run-time
+// value (loops not unrolled, spatial exponent computed per tap row).  8 waves x 2 rows per workgroup.
+template <int FMT, bool LINEAR, int MODE>
+__global__ __launch_bounds__(512) void bilateral_rt_kernel(const BilArgs a, const int R)
+{
+    constexpr int NW = 8, P = 2, TILE_W = 64, TILE_H = NW * P;
+    const int LW = TILE_W + 2 * R, LH = TILE_H + 2 * R;
+    extern __shared__ float4 lds[];
+    float4 *img_t = lds;
+    float4 *gde_t = (MODE == 0) ? lds : lds + LW * LH;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned flat = xcd_remap_b(blockIdx.x, gridDim.x);
+    const int ty = (int)(flat / (unsigned)a.tiles_x), tx = (int)(flat - (unsigned)ty * a.tiles_x);
+    const int w = a.w, h = a.h;
+    const int X0 = tx * TILE_W, Y0 = ty * TILE_H;
+    const int gx = X0 + lane, yb = Y0 + wv * P;
+    const bool wave_active = yb < h;
+
+    fill_tile<FMT, LINEAR>(img_t, LW, LH, a.in, w, h, X0 - R, Y0 - R, tid, NW * 64);
+    float4 tot[P];
+    float totw[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) { tot[k] = make_float4(0.f, 0.f, 0.f, 0.f); totw[k] = 0.f; }
+    const int n_pass = (MODE == 2) ? a.n_layers : 1;
+    for (int pass = 0; pass < n_pass; ++pass) {
+        if (MODE != 0) {
+            __syncthreads();
+            fill_tile<MID_FMT_RGBA8, false>(gde_t, LW, LH, a.layers[pass], w, h, X0 - R, Y0 - R, tid, NW * 64);
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+        float cr[P], cg[P], cb[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const float4 c = gde_t[(wv * P + k + R) * LW + lane + R];
+            cr[k] = c.x; cg[k] = c.y; cb[k] = c.z;
+        }
+        float4 acc[P];
+        float accw[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) { acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); accw[k] = 0.f; }
+        for (int i = -R; i <= R; ++i) {
+            const float si = a.ks * (float)(i * i);
+            const int base = (wv * P) * LW + lane + R + i;
+            for (int m = 0; m < P + 2 * R; ++m) {
+                const float4 g = gde_t[base + m * LW];
+                float4 c = g;
+                if (MODE != 0) c = img_t[base + m * LW];
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    const int j = m - R - k;
+                    if (j < -R || j > R) continue;               // wave-uniform
+                    const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
+                    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    const float wt = __builtin_amdgcn_exp2f(fmaf(d2, a.kc, fmaf(a.ks, (float)(j * j), si)));
+                    acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
+                    acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
+                    accw[k] += wt;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            tot[k].x += acc[k].x; tot[k].y += acc[k].y; tot[k].z += acc[k].z; tot[k].w += acc[k].w;
+            totw[k] += accw[k];
+        }
+    }
+    if (!wave_active || gx >= w) return;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const int gy = yb + k;
+        if (gy >= h) break;
+        const size_t idx = (size_t)gy * w + gx;
+        if (MODE == 1) {
+            float4 *wp = (float4 *)(a.W + idx);
+            float4 wc = wp[0], nw = wp[1];
+            wc.x += tot[k].x; wc.y += tot[k].y; wc.z += tot[k].z; wc.w += tot[k].w;
+            nw.x += totw[k];
+            wp[0] = wc; wp[1] = nw;
+        } else {
+            float4 o;
+            if (MODE == 2 && totw[k] == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);
+            else o = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
+            a.out[idx] = o;
+        }
+    }
+}
+
+// Last resort (tile does not fit LDS): one thread per pixel, global fetches.
 template <int FMT, bool LINEAR, int MODE>
 __global__ __launch_bounds__(256) void bilateral_generic_kernel(const BilArgs a, int R)
 {
@@ -225,6 +313,18 @@ static int dispatch_radius(mid_ctx *ctx, int radius, BilArgs &a, hipStream_t s)
         if (MODE == 0) return launch_tiled<20, 1, 16, FMT, LINEAR, MODE>(ctx, a, s);
         return launch_tiled<20, 1, 8, FMT, LINEAR, MODE>(ctx, a, s);          // two tiles (image + guide) must fit 160 KB
     default: break;
+    }
+    {   // run-time radius, LDS tiled
+        const size_t lds_bytes = (size_t)(64 + 2 * radius) * (16 + 2 * radius) * sizeof(float4) * (MODE == 0 ? 1 : 2);
+        if ((int)lds_bytes <= ctx->lds_max) {
+            auto kern = bilateral_rt_kernel<FMT, LINEAR, MODE>;
+            if (int rc = ensure_lds(ctx, (const void *)kern, (size_t)ctx->lds_max)) return rc;
+            a.tiles_x = (int)cdiv(a.w, 64);
+            a.tiles_y = (int)cdiv(a.h, 16);
+            hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles_x * a.tiles_y), dim3(512), lds_bytes, s, a, radius);
+            MID_HIP(hipGetLastError());
+            return MID_OK;
+        }
     }
     dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16));
     hipLaunchKernelGGL((bilateral_generic_kernel<FMT, LINEAR, MODE>), grid, dim3(256), 0, s, a, radius);

@@ -29,6 +29,7 @@ struct NlmArgs {
     const void *target;
     const void *neighbour;
     mid_weightinfo *W;
+    int slo, shi;          // run-time search range of the RTS instantiations
     // fused temporal mode
     int n_frames, k, first, count;
     FrameTable frames;
@@ -90,14 +91,19 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
 template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 {
-    constexpr int SW = SHI - SLO, PW = PHI - PLO;
+    // SLO == SHI == 0 selects the run-time search range [a.slo, a.shi) (any window, same patch):
+    // LDS pitch and loop bounds then come from the arguments instead of being folded constants.
+    constexpr bool RTS = (SLO == 0 && SHI == 0);
+    constexpr int PW = PHI - PLO;
     constexpr int DR = R + PW - 1;
     constexpr int NL = -PLO, NR = PHI - 1;
     constexpr int VW = 64 - (PW - 1);
     constexpr int TILE_H = NW * R;
-    constexpr int LW = 64 + SW - 1;
-    constexpr int LH = TILE_H + PW - 1 + SW - 1;
-    static_assert(PLO <= 0 && PHI >= 1 && SW >= 1, "ranges must contain 0");
+    const int slo = RTS ? a.slo : SLO;
+    const int SW = RTS ? a.shi - a.slo : SHI - SLO;
+    const int LW = 64 + SW - 1;
+    const int LH = TILE_H + PW - 1 + SW - 1;
+    static_assert(PLO <= 0 && PHI >= 1 && (RTS || SHI - SLO >= 1), "ranges must contain 0");
 
     extern __shared__ float4 lds[];
 
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
     for (int f = f_lo; f <= f_hi; ++f) {
         const void *nb = FUSED ? a.frames.p[f] : a.neighbour;
         __syncthreads();   // previous frame's readers are done with the tile
-        fill_tile<FMT, false>(lds, LW, LH, nb, w, h, X0 + PLO + SLO, Y0 + PLO + SLO, tid, NW * 64);
+        fill_tile<FMT, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo, tid, NW * 64);
         __syncthreads();
         if (!wave_active) continue;
 
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
                     __builtin_amdgcn_sched_barrier(0);
                     compute(B);
                 }
-                if constexpr (SW & 1) compute(A);
+                if (SW & 1) compute(A);
             } else {
 #pragma unroll U
                 for (int sx = 0; sx < SW; ++sx) {
@@ -298,10 +304,12 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
 template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool PIPE = false>
 static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
 {
-    constexpr int SW = SHI - SLO, PW = PHI - PLO;
+    constexpr bool RTS = (SLO == 0 && SHI == 0);
+    constexpr int PW = PHI - PLO;
     constexpr int VW = 64 - (PW - 1), TILE_H = NW * R;
-    constexpr int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + SW - 1;
-    constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
+    const int SW = RTS ? a.shi - a.slo : SHI - SLO;
+    const int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + SW - 1;
+    const size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
     auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, PIPE>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
@@ -317,11 +325,23 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
 template <int FMT, bool FUSED>
 static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s)
 {
-    // Tile shapes were chosen by A/B on MI355X (tools/ab_nlm.py): 4 waves x 8 rows per
-    // workgroup = 76 KB of LDS, so two workgroups share a CU and one computes while the other
+    // Tile shapes were chosen by A/B on MI355X (tools/ab_nlm.py): 4 waves x R rows per
+    // workgroup (R=8: 76 KB of LDS), so two workgroups share a CU and one computes while the other
     // refills its tile; the search-column loop is unrolled 7x (21 = 3*7) / 2x (14 = 2*7).
+    // R=8 has the least redundant work per pixel; R=6 makes smaller workgroups.  All workgroups cost the
+    // same, so a launch takes ceil(workgroups / resident slots) rounds: pick the R whose
+    // rounds x (work per workgroup) is smallest -- for ONE 1080p frame R=8 needs 3 rounds of 512 slots for
+    // 2.26 rounds of work, R=6 fills 3 rounds almost exactly with 21 % less work in each.
     const bool multi = FUSED && a.k > 0;
     static const int variant = getenv("MID_NLM_VARIANT") ? atoi(getenv("MID_NLM_VARIANT")) : 0;   // tuning A/B only
+    const int pw = p->patch_hi - p->patch_lo;
+    auto rounds_cost = [&](int R) {     // relative launch time of a 4-wave, 2-workgroups-per-CU tiling
+        const long wgs = (long)cdiv(a.w, 64 - (pw - 1)) * cdiv(a.h, 4 * R) * (FUSED ? a.count : 1);
+        const long slots = 2L * ctx->cu_count, rounds = (wgs + slots - 1) / slots;
+        const double per_out = 6.0 * (R + pw - 1) / R + (4.0 * R + 4) / R + 10.5 + 4.2 + 5.0;   // VALU units, DESIGN.md 3.1
+        return (double)rounds * R * per_out;
+    };
+    const bool small_r = !multi && variant == 0 && rounds_cost(6) < 0.97 * rounds_cost(8);
     if (p->search_lo == -10 && p->search_hi == 11 && p->patch_lo == -3 && p->patch_hi == 4) {   // 21x21 / 7x7 (benchmark)
         if (multi) {
             if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, FUSED, 1>(ctx, a, s);
@@ -331,14 +351,30 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
         if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, false, 3>(ctx, a, s);
         if (variant == 2) return launch_strip<-10, 11, -3, 4, 7, 12, FMT, FUSED, false, 3>(ctx, a, s);
         if (variant == 3) return launch_strip<-10, 11, -3, 4, 5, 16, FMT, FUSED, false, 3>(ctx, a, s);
-        if (variant == 4) return launch_strip<-10, 11, -3, 4, 7, 4, FMT, FUSED, false, 3>(ctx, a, s);
+        if (variant == 4) return launch_strip<-10, 11, -3, 4, 7, 4, FMT, FUSED, false, 7>(ctx, a, s);
         if (variant == 5) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s);
-        if (variant == 6) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 1, true>(ctx, a, s);
+        if (variant == 6) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7>(ctx, a, s);
+        if (variant == 8 || small_r) return launch_strip<-10, 11, -3, 4, 6, 4, FMT, FUSED, false, 7>(ctx, a, s);
         return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7>(ctx, a, s);
     }
     if (p->search_lo == -7 && p->search_hi == 7 && p->patch_lo == -3 && p->patch_hi == 3) {     // nonlocal.comp:5-6 as shipped
         if (multi) return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, FUSED, 2>(ctx, a, s);
+        if (small_r) return launch_strip<-7, 7, -3, 3, 6, 4, FMT, FUSED, false, 2>(ctx, a, s);
         return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2>(ctx, a, s);
+    }
+    // Any other search window with one of the common patches: the same strip kernel with the search
+    // range as a run-time argument (LDS pitch no longer a folded constant: a few % slower).
+    a.slo = p->search_lo; a.shi = p->search_hi;
+    {
+        const int sw = p->search_hi - p->search_lo;
+        auto fits = [&](int pw_) { return (size_t)(64 + sw - 1) * (32 + pw_ - 1 + sw - 1) * sizeof(float4) <= (size_t)ctx->lds_max; };
+#define MID_NLM_RT(PLO_, PHI_)                                                                              \
+        if (p->patch_lo == (PLO_) && p->patch_hi == (PHI_) && fits((PHI_) - (PLO_))) {                          \
+            if (multi) return launch_strip<0, 0, PLO_, PHI_, 8, 4, FMT, FUSED, FUSED, 1>(ctx, a, s);            \
+            return launch_strip<0, 0, PLO_, PHI_, 8, 4, FMT, FUSED, false, 1>(ctx, a, s);                       \
+        }
+        MID_NLM_RT(-3, 4) MID_NLM_RT(-3, 3) MID_NLM_RT(-2, 3) MID_NLM_RT(-1, 2) MID_NLM_RT(-4, 5)
+#undef MID_NLM_RT
     }
     dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16), FUSED ? a.count : 1);
     hipLaunchKernelGGL((nlm_generic_kernel<FMT, FUSED>), grid, dim3(256), 0, s, a,

@@ -27,7 +27,7 @@ def test_native_library_is_the_thing_under_test(ctx):
 
 # ---- a1 / a2 -------------------------------------------------------------------------------------
 @pytest.mark.parametrize("layout", ["texture", "linear"])
-@pytest.mark.parametrize("R", [1, 3, 4, 8, 10, 20, 24])       # 4/8/10/20 tuned tiles, others generic kernel
+@pytest.mark.parametrize("R", [1, 3, 4, 6, 8, 10, 13, 20, 24])  # 4/8/10/20 tuned tiles, others the run-time-radius kernel
 def test_bilateral_hdr(ctx, layout, R):
     rng = np.random.default_rng(R)
     h, w = (70, 131) if R < 20 else (75, 140)                  # not multiples of the tile, > 1 tile each way
@@ -61,7 +61,7 @@ def test_bilateral_sigma_sweep(ctx):
 
 
 # ---- a3 -------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("R", [4, 8, 6])
+@pytest.mark.parametrize("R", [4, 8, 6, 16, 22])               # 22: two tiles exceed LDS -> per-pixel fallback
 def test_layers_accumulate_and_fused(ctx, R):
     rng = np.random.default_rng(20 + R)
     h, w = 50, 90
@@ -88,7 +88,10 @@ def test_layers_ldr_input_and_no_layers(ctx):
 
 # ---- a4 -------------------------------------------------------------------------------------------
 NLM_CFGS = {"ref": dict(search=(-7, 7), patch=(-3, 3)), "bench": dict(search=(-10, 11), patch=(-3, 4)),
-            "generic": dict(search=(-3, 4), patch=(-1, 2))}
+            "generic": dict(search=(-3, 4), patch=(-1, 2)),           # run-time search range, 3x3 patch
+            "rt7": dict(search=(-6, 9), patch=(-3, 4)),               # run-time (asymmetric) search, 7x7 patch
+            "rt5": dict(search=(-12, 13), patch=(-2, 3)),             # 25x25 search, 5x5 patch
+            "naive": dict(search=(-2, 3), patch=(-2, 2))}             # 4x4 patch: one-thread-per-pixel fallback
 
 
 def _nlm_pair(rng, h, w, scale=0.25):
@@ -97,14 +100,17 @@ def _nlm_pair(rng, h, w, scale=0.25):
     return t, nb
 
 
-@pytest.mark.parametrize("cfg", ["ref", "bench", "generic"])
+@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "naive"])
 def test_nlm_accum(ctx, cfg):
     rng = np.random.default_rng(40)
     h, w = 71, 125                                   # > 1 tile in x (58/59 px) and y (64 px), ragged
     t, nb = _nlm_pair(rng, h, w)
     W0 = rng.random((h, w, 8), dtype=np.float32)     # the dispatch ADDS to whatever W holds
     Wg, Wo = ctx.nlm_accum(t, nb, W0, 0.5, **NLM_CFGS[cfg]), oracle.nlm_accum(t, nb, W0, 0.5, **NLM_CFGS[cfg])
-    assert rel_err(Wg[..., :5], Wo[..., :5]) < NLM_TOL
+    # 625 offsets x 5x5 patch: measured against float64, the oracle (reference loop order) and the kernel are
+    # EACH within 1.3e-5 of the exact sums, on opposite sides -- two fp32 evaluations can differ by 2.6e-5.
+    tol = 5e-5 if cfg == "rt5" else NLM_TOL
+    assert rel_err(Wg[..., :5], Wo[..., :5]) < tol
     assert np.array_equal(Wg[..., 5:], W0[..., 5:]), "std430 padding is never written"
 
 
@@ -135,7 +141,7 @@ def test_nlm_ldr_input(ctx):
     assert rel_err(ctx.nlm_accum(a, b, Z(37, 64), 0.5)[..., :5], ref[..., :5]) < NLM_TOL
 
 
-@pytest.mark.parametrize("cfg", ["ref", "bench", "generic"])
+@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "naive"])
 def test_nlm_temporal_fused_equals_dispatch_sequence(ctx, cfg):
     """mid_nlm_temporal(k) == for each neighbour frame: mid_nlm_accum; then mid_normalize -- bit for
     bit -- and both match the oracle; windows clip at the sequence ends (5 frames, k=2)."""

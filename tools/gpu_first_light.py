@@ -64,3 +64,10 @@ for name, cfg in (("ref", mid.NLM_REFERENCE), ("bench", mid.NLM_BENCH)):
         outs = [ctx.alloc(H * Wd * 16) for _ in range(nfr)]
         ms = timeit(lambda: ctx.nlm_temporal_dev([d_in.ptr] * nfr, [o.ptr for o in outs], Wd, H, 0.5, cfg["search"], cfg["patch"], 0, 0, nfr, 0), n=3)
         print(f"nlm {name} batch={nfr}: {ms:.3f} ms  {nfr*H*Wd/ms/1e3:.0f} Mpx/s")
+for R in (5, 6, 12, 16, 24):
+    ms = timeit(lambda: ctx.bilateral_dev(d_in.ptr, d_out.ptr, Wd, H, R, 2.0, 0.2, 0, 0))
+    print(f"bilateral (run-time radius kernel) r={R}: {ms:.3f} ms  {H*Wd/ms/1e3:.0f} Mpx/s")
+for name, cfg in (("15x15/5x5", dict(search=(-7, 8), patch=(-2, 3))), ("11x11/3x3", dict(search=(-5, 6), patch=(-1, 2))), ("25x25/7x7", dict(search=(-12, 13), patch=(-3, 4))), ("9x9/4x4 (generic)", dict(search=(-4, 5), patch=(-2, 2)))):
+    o = ctx.alloc(H * Wd * 16)
+    ms = timeit(lambda: ctx.nlm_temporal_dev([d_in.ptr], [o.ptr], Wd, H, 0.5, cfg["search"], cfg["patch"], 0, 0, 1, 0), n=3)
+    print(f"nlm {name}: {ms:.3f} ms  {H*Wd/ms/1e3:.0f} Mpx/s")

@@ -154,6 +154,7 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
     if (compression > 3) { err = std::string("exr: compression ") + (compression < 10 ? cname[compression] : "?") + " is not supported (NONE/RLE/ZIPS/ZIP only)"; return false; }
     const long W = (long)dw[2] - dw[0] + 1, H = (long)dw[3] - dw[1] + 1;
     if (W <= 0 || H <= 0 || W > 65536 || H > 65536) { err = "exr: bad data window"; return false; }
+    if ((double)W * H * 2 > (double)file.size() * 1100.0) { err = "exr: data window larger than the file can hold"; return false; }
     size_t line_bytes = 0;
     std::vector<size_t> choff(chans.size());
     for (size_t c = 0; c < chans.size(); ++c) {

@@ -3,6 +3,7 @@
 #include "image_io.hpp"
 
 #include <cstdlib>
+#include <exception>
 
 using namespace mid;
 
@@ -23,6 +24,7 @@ extern "C" int mid_image_load(const char *path, mid_image *out)
     std::string err;
     if (!codec::read_file(path, file, err)) return set_error(MID_ERR_IO, "%s", err.c_str());
     int w = 0, h = 0;
+    try {   // a corrupt header can ask for an absurd allocation: no exception may cross the C ABI
     if (has_ext(path, ".exr")) {                      // m_isHDR = extension == ".exr", src/main.cpp:1380
         std::vector<float> px;
         if (!codec::exr_decode(file, w, h, px, err)) return set_error(MID_ERR_IO, "%s: %s", path, err.c_str());
@@ -37,6 +39,9 @@ extern "C" int mid_image_load(const char *path, mid_image *out)
         if (!out->data) return set_error(MID_ERR_IO, "out of host memory");
         memcpy(out->data, px.data(), px.size());
         out->format = MID_FMT_RGBA8;
+    }
+    } catch (const std::exception &e) {
+        return set_error(MID_ERR_IO, "%s: %s", path, e.what());
     }
     out->width = w; out->height = h;
     return MID_OK;
@@ -53,10 +58,14 @@ extern "C" int mid_image_save(const char *path, const void *data, int32_t w, int
     std::vector<uint8_t> file;
     std::string err;
     bool ok;
+    try {
     if (format == MID_FMT_RGBA32F) ok = codec::exr_encode((const float *)data, w, h, file, err);
     else if (format == MID_FMT_RGBA8) ok = codec::png_encode((const uint8_t *)data, w, h, file, err);
     else return set_error(MID_ERR_INVALID, "image_save: unknown format %d", format);
     if (!ok) return set_error(MID_ERR_IO, "%s: %s", path, err.c_str());
     if (!codec::write_file(path, file, err)) return set_error(MID_ERR_IO, "%s", err.c_str());
+    } catch (const std::exception &e) {
+        return set_error(MID_ERR_IO, "%s: %s", path, e.what());
+    }
     return MID_OK;
 }

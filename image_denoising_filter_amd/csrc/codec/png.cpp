@@ -139,6 +139,7 @@ bool png_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<ui
     }
     if (!seen_ihdr || !seen_iend || idat.empty()) { err = "png: missing IHDR/IDAT/IEND"; return false; }
     if (pi.w == 0 || pi.h == 0 || pi.w > 65536 || pi.h > 65536) { err = "png: bad dimensions"; return false; }
+    if ((double)pi.w * pi.h / 8 > (double)idat.size() * 1100.0) { err = "png: dimensions larger than the data can hold"; return false; }
     const int d = pi.depth, t = pi.ctype;
     const bool ok = (t == 0 && (d == 1 || d == 2 || d == 4 || d == 8 || d == 16)) || (t == 3 && (d == 1 || d == 2 || d == 4 || d == 8)) ||
                     ((t == 2 || t == 4 || t == 6) && (d == 8 || d == 16));

@@ -1,0 +1,52 @@
+// codec_sanitize.cpp -- AddressSanitizer/UBSan sweep of the PNG/EXR decoders on the CPU build
+// (GPU sanitizers are not available on this pool).  Encodes a few images, then feeds every prefix
+// and thousands of single-byte corruptions of each file to the decoders.  Built and run by
+// tests/test_codecs.py::test_sanitizer_sweep with -fsanitize=address,undefined.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../image_denoising_filter_amd/csrc/codec/image_io.hpp"
+
+using namespace mid::codec;
+
+int main()
+{
+    std::mt19937 rng(1234);
+    long decoded = 0, rejected = 0;
+    for (int trial = 0; trial < 6; ++trial) {
+        const int w = 1 + rng() % 40, h = 1 + rng() % 40;
+        std::vector<uint8_t> px8((size_t)w * h * 4);
+        std::vector<float> pxf((size_t)w * h * 4);
+        for (auto &v : px8) v = (uint8_t)rng();
+        for (auto &v : pxf) v = (float)(rng() % 10000) / 1000.0f;
+        std::vector<uint8_t> png, exr;
+        std::string err;
+        if (!png_encode(px8.data(), w, h, png, err) || !exr_encode(pxf.data(), w, h, exr, err)) { printf("encode failed: %s\n", err.c_str()); return 1; }
+        for (int kind = 0; kind < 2; ++kind) {
+            const std::vector<uint8_t> &good = kind ? exr : png;
+            auto decode = [&](const std::vector<uint8_t> &f) {
+                int ww, hh;
+                std::string e;
+                bool ok;
+                if (kind) { std::vector<float> o; ok = exr_decode(f, ww, hh, o, e); }
+                else { std::vector<uint8_t> o; ok = png_decode(f, ww, hh, o, e); }
+                ok ? ++decoded : ++rejected;
+                return ok;
+            };
+            if (!decode(good)) { printf("valid file rejected\n"); return 1; }
+            for (size_t n = 0; n < good.size(); n += (n < 512 ? 1 : 61)) {
+                std::vector<uint8_t> cut(good.begin(), good.begin() + n);
+                if (decode(cut)) { printf("truncated file accepted (%zu of %zu)\n", n, good.size()); return 1; }
+            }
+            for (int i = 0; i < 3000; ++i) {
+                std::vector<uint8_t> bad = good;
+                const int nflip = 1 + rng() % 3;
+                for (int k = 0; k < nflip; ++k) bad[rng() % bad.size()] ^= (uint8_t)(1 + rng() % 255);
+                decode(bad);
+            }
+        }
+    }
+    printf("sanitizer sweep done: %ld decoded, %ld rejected\n", decoded, rejected);
+    return 0;
+}

@@ -257,11 +257,13 @@ class Context:
                                       out.ctypes.data, 1 if overlap else 0, t), "mid_nlm_multiframe")
         return out, tuple(t)
 
-    def sequence_nlm(self, frames, k=2, overlap=True, hparam=0.5, search=(-7, 7), patch=(-3, 3), pinned=True):
-        """Host frames in, host frames out through the 3-stream pipeline (mid_sequence_nlm).
-        Returns (outputs, (wall_ms, kernel_ms, copy_ms))."""
+    def sequence_nlm(self, frames, k=2, overlap=True, hparam=0.5, search=(-7, 7), patch=(-3, 3), pinned=True,
+                     first=0, count=None):
+        """Host frames in, host frames out through the 3-stream pipeline (mid_sequence_nlm[_range]).
+        Returns (outputs for frames first..first+count-1, (wall_ms, kernel_ms, copy_ms))."""
         frames = [_img(f) for f in frames]
         n = len(frames)
+        count = n - first if count is None else count
         h, w = frames[0].shape[:2]
         fmt = _fmt_of(frames[0])
         in_bytes, out_bytes = frames[0].nbytes, w * h * 16
@@ -275,13 +277,14 @@ class Context:
                     hin.append(p.value)
                 else:
                     hin.append(f.ctypes.data)
+            for _ in range(count):
                 q = ctypes.c_void_p()
                 _check(lib.mid_alloc_host(self.handle, out_bytes, ctypes.byref(q)), "mid_alloc_host")
                 hout.append(q.value)
             prm = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], fmt)
             t = (ctypes.c_float * 3)()
-            _check(lib.mid_sequence_nlm(self.handle, ctypes.byref(prm), (ctypes.c_void_p * n)(*hin), n, k,
-                                        (ctypes.c_void_p * n)(*hout), 1 if overlap else 0, t), "mid_sequence_nlm")
+            _check(lib.mid_sequence_nlm_range(self.handle, ctypes.byref(prm), (ctypes.c_void_p * n)(*hin), n, k, first, count,
+                                              (ctypes.c_void_p * count)(*hout), 1 if overlap else 0, t), "mid_sequence_nlm_range")
             outs = []
             for q in hout:
                 o = np.empty((h, w, 4), np.float32)

@@ -26,6 +26,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/mi_denoise.h"
@@ -54,6 +55,8 @@ struct Options {
     std::vector<int> cpu_threads = {1, 8};     // src/main.cpp:1979,1984
     bool run_gpu = true, run_cpu = true;
     std::string modes = "all";      // comma list of: bilateral,layers,linear,nlm,multiframe,overlap
+    bool animation = false;         // new capability: temporal NLM of EVERY frame of the sequence
+    int gpus = 1;                   // animation mode: frame blocks over this many devices
 };
 
 #define MID_CHECK(call)                                                                          \
@@ -267,6 +270,61 @@ public:
         std::cout << "\tcleaning up\n";
     }
 
+    // Animation mode (BASELINE config 5; not in the reference, which filters one target per run): every
+    // sibling frame of the target is denoised with temporal NLM over frames t-k..t+k.  Frames are split
+    // into contiguous blocks, one per device; each device streams its block plus k halo frames on either
+    // side through the 3-stream pipeline (mid_sequence_nlm_range).  All frames sit in host memory here, so
+    // the halo needs no device-to-device exchange (bench.py / sharding.py cover the RCCL case, where
+    // frames are GPU-resident).  Outputs: output-animation-<frame file name>.
+    void RunAnimation()
+    {
+        std::vector<std::string> frameNames, layerNames;
+        discover(frameNames, layerNames, true, false);
+        if (frameNames.empty()) throw std::runtime_error("no frames next to " + opt.image);
+        const int n = (int)frameNames.size(), k = opt.temporal_k < 0 ? 2 : opt.temporal_k;
+        std::cout << "\tloading " << n << " frames\n";
+        std::vector<HostImage> frames;
+        for (auto &f : frameNames) {
+            frames.push_back(load(f, false));
+            if (frames.back().w != frames[0].w || frames.back().h != frames[0].h || frames.back().format != frames[0].format)
+                throw std::runtime_error(f + ": size/format differs from the first frame");
+        }
+        const int w = frames[0].w, h = frames[0].h, fmt = frames[0].format;
+        std::vector<const void *> in(n);
+        std::vector<std::vector<Pixel>> out(n, std::vector<Pixel>((size_t)w * h));
+        for (int i = 0; i < n; ++i) in[i] = frames[i].bytes.data();
+        const int G = std::max(1, std::min(opt.gpus, n));
+        std::vector<std::string> errors(G);
+        std::vector<float> kern(G, 0.f), copy(G, 0.f);
+        std::vector<std::thread> workers;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int g = 0; g < G; ++g)
+            workers.emplace_back([&, g] {
+                try {
+                    const int q = n / G, r = n % G, start = g * q + std::min(g, r), count = q + (g < r ? 1 : 0);
+                    if (count == 0) return;
+                    mid_ctx *ctx = nullptr;
+                    MID_CHECK(mid_ctx_create(opt.device + g, &ctx));
+                    struct CtxGuard { mid_ctx *c; ~CtxGuard() { mid_ctx_destroy(c); } } guard{ctx};
+                    mid_nlm_params p{w, h, opt.nlm_h, opt.search_lo, opt.search_hi, opt.patch_lo, opt.patch_hi, fmt};
+                    std::vector<mid_pixel *> o(count);
+                    for (int i = 0; i < count; ++i) o[i] = (mid_pixel *)out[start + i].data();
+                    float t[3] = {0, 0, 0};
+                    MID_CHECK(mid_sequence_nlm_range(ctx, &p, in.data(), n, k, start, count, o.data(), 1, t));
+                    kern[g] = t[1]; copy[g] = t[2];
+                } catch (const std::exception &e) { errors[g] = e.what(); }
+            });
+        for (auto &t : workers) t.join();
+        for (auto &e : errors) if (!e.empty()) throw std::runtime_error(e);
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        m_execMs = *std::max_element(kern.begin(), kern.end());
+        m_transferMs = *std::max_element(copy.begin(), copy.end());
+        std::cout << "\t" << n << " frames, k=" << k << ", " << G << " device(s): " << sec << " sec, "
+                  << (double)n * w * h / 1e6 / sec << " Mpixel/s end to end\n";
+        const bool hdr = fmt == MID_FMT_RGBA32F;
+        for (int i = 0; i < n; ++i) save("output-animation-" + fs::path(frameNames[i]).stem().string(), out[i], w, h, hdr);
+    }
+
     void save(std::string name, const std::vector<Pixel> &px, int w, int h, bool hdr) const
     {
         if (hdr) {
@@ -324,6 +382,8 @@ static void usage()
         "  --nlm-h H                 NLM filtering parameter (default 0.5)\n"
         "  --search LO,HI --patch LO,HI   half-open NLM ranges (default -7,7 and -3,3; 21x21/7x7 is -10,11 and -3,4)\n"
         "  --temporal-k K            multiframe: frames t-K..t+K of the sorted sequence instead of the reference's list\n"
+        "  --animation               denoise EVERY sibling frame with temporal NLM (window +-K, default 2) instead of the mode list\n"
+        "  --gpus N                  animation mode: split the sequence into N frame blocks, one per device\n"
         "  --cpu-radius R --cpu-sigma-s S --cpu-sigma-c C   CPU path (default 10 10.0 0.2)\n"
         "  --cpu-threads A,B         thread counts of the CPU runs (default 1,8)\n"
         "  --cpu-fix-blue            use the blue channel in the CPU range distance (the reference does not)\n";
@@ -351,6 +411,8 @@ int main(int argc, char **argv)
         else if (a == "--search") { if (!pair_arg(next(), opt.search_lo, opt.search_hi)) { usage(); return EXIT_FAILURE; } }
         else if (a == "--patch") { if (!pair_arg(next(), opt.patch_lo, opt.patch_hi)) { usage(); return EXIT_FAILURE; } }
         else if (a == "--temporal-k") opt.temporal_k = atoi(next());
+        else if (a == "--animation") opt.animation = true;
+        else if (a == "--gpus") opt.gpus = atoi(next());
         else if (a == "--cpu-radius") opt.cpu_radius = atoi(next());
         else if (a == "--cpu-sigma-s") opt.cpu_sigma_s = (float)atof(next());
         else if (a == "--cpu-sigma-c") opt.cpu_sigma_c = (float)atof(next());
@@ -372,6 +434,12 @@ int main(int argc, char **argv)
             std::cout << FOREGROUND_COLOR << BACKGROUND_COLOR << "transfer time: " << (unsigned long long)(app.GetTransferMs() * 1e6) << "ns; "
                       << "execution time: " << (unsigned long long)(app.GetExecMs() * 1e6) << "ns\n\n" << CLEAR_COLOR;
         };
+        if (opt.animation) {
+            std::cout << "######\nRunning on GPU (animation, temporal nonlocal)\n######\n";
+            app.RunAnimation();
+            print_time();
+            return EXIT_SUCCESS;
+        }
         if (opt.run_gpu) {
             if (want("bilateral")) { std::cout << "######\nRunning on GPU (nonlinear bialteral)\n######\n"; app.RunOnGPU(false, true, false, false, false); print_time(); }
             if (want("layers")) { std::cout << "######\nRunning on GPU (nonlinear bialteral + layers)\n######\n"; app.RunOnGPU(false, true, false, false, true); print_time(); }

@@ -53,63 +53,74 @@ struct DeviceBufs {
 
 }  // namespace
 
-extern "C" int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
-                                int n, int k, mid_pixel *const *host_out, int overlap, float *timings_ms)
+// Outputs [first, first+count) of an n-frame host sequence; frames outside that range are only
+// uploaded as far as the temporal window needs them (the halo of a frame block).
+extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
+                                      int n, int k, int first, int count, mid_pixel *const *host_out,
+                                      int overlap, float *timings_ms)
 {
     Bind b(ctx, nullptr);
     if (b.rc) return b.rc;
     MID_REQUIRE(p && host_frames && host_out, "sequence_nlm: NULL argument");
     MID_REQUIRE(n >= 1 && k >= 0 && 2 * k + 2 <= kMaxFrames, "sequence_nlm: bad n=%d k=%d", n, k);
+    MID_REQUIRE(first >= 0 && count >= 1 && first + count <= n, "sequence_nlm: bad range first=%d count=%d n=%d", first, count, n);
     MID_REQUIRE(p->width > 0 && p->height > 0, "sequence_nlm: bad size");
-    for (int i = 0; i < n; ++i) MID_REQUIRE(host_frames[i] && host_out[i], "sequence_nlm: frame %d is NULL", i);
+    const int f_lo = first - k < 0 ? 0 : first - k;                                  // first frame ever uploaded
+    const int f_hi = first + count - 1 + k > n - 1 ? n - 1 : first + count - 1 + k;  // last one
+    for (int i = f_lo; i <= f_hi; ++i) MID_REQUIRE(host_frames[i], "sequence_nlm: frame %d is NULL", i);
+    for (int i = 0; i < count; ++i) MID_REQUIRE(host_out[i], "sequence_nlm: output %d is NULL", i);
 
     const size_t npix = (size_t)p->width * p->height;
     const size_t in_bytes = npix * (p->format == MID_FMT_RGBA8 ? 4 : 16), out_bytes = npix * 16;
-    const int ring = n < 2 * k + 2 ? n : 2 * k + 2;
+    const int n_up = f_hi - f_lo + 1;
+    const int ring = n_up < 2 * k + 2 ? n_up : 2 * k + 2;
 
     DeviceBufs dring, dout;
     if (int rc = dring.make(ring, in_bytes)) return rc;
     if (int rc = dout.make(2, out_bytes)) return rc;
     EventPool up0, up1, c0, c1, d0, d1;
-    for (EventPool *e : {&up0, &up1, &c0, &c1, &d0, &d1})
-        if (int rc = e->make(n)) return rc;
+    for (EventPool *e : {&up0, &up1}) if (int rc = e->make(n_up)) return rc;
+    for (EventPool *e : {&c0, &c1, &d0, &d1}) if (int rc = e->make(count)) return rc;
+    auto slot = [&](int f) { return dring.p[(f - f_lo) % ring]; };
 
     const auto wall0 = std::chrono::steady_clock::now();
-    int next_upload = 0;
+    int next_upload = f_lo;
     auto upload = [&](int f) -> int {
-        if (f >= ring) {   // the slot still holds frame f-ring, last read by output (f-ring)+k
-            const int last_reader = f - ring + k < n - 1 ? f - ring + k : n - 1;
-            MID_HIP(hipStreamWaitEvent(ctx->upload, c1.ev[last_reader], 0));
+        if (f - f_lo >= ring) {   // the slot still holds frame f-ring, last read by output (f-ring)+k
+            int last_reader = f - ring + k;
+            if (last_reader > first + count - 1) last_reader = first + count - 1;
+            if (last_reader >= first) MID_HIP(hipStreamWaitEvent(ctx->upload, c1.ev[last_reader - first], 0));
         }
-        MID_HIP(hipEventRecord(up0.ev[f], ctx->upload));
-        MID_HIP(hipMemcpyAsync(dring.p[f % ring], host_frames[f], in_bytes, hipMemcpyHostToDevice, ctx->upload));
-        MID_HIP(hipEventRecord(up1.ev[f], ctx->upload));
+        MID_HIP(hipEventRecord(up0.ev[f - f_lo], ctx->upload));
+        MID_HIP(hipMemcpyAsync(slot(f), host_frames[f], in_bytes, hipMemcpyHostToDevice, ctx->upload));
+        MID_HIP(hipEventRecord(up1.ev[f - f_lo], ctx->upload));
         return MID_OK;
     };
 
-    for (int t = 0; t < n; ++t) {
+    for (int t = first; t < first + count; ++t) {
+        const int i = t - first;
         const int need = t + k < n - 1 ? t + k : n - 1;
-        const int ahead = overlap ? (need + 1 < n - 1 ? need + 1 : n - 1) : need;
+        const int ahead = overlap ? (need + 1 < f_hi ? need + 1 : f_hi) : need;
         // frames up to t+k must be resident; with overlap also start frame t+k+1 now, it only
         // waits for compute(t-1) and then runs beside compute(t)
         while (next_upload <= need) { if (int rc = upload(next_upload++)) return rc; }
-        MID_HIP(hipStreamWaitEvent(ctx->compute, up1.ev[need], 0));
-        if (t >= 2) MID_HIP(hipStreamWaitEvent(ctx->compute, d1.ev[t - 2], 0));
+        MID_HIP(hipStreamWaitEvent(ctx->compute, up1.ev[need - f_lo], 0));
+        if (i >= 2) MID_HIP(hipStreamWaitEvent(ctx->compute, d1.ev[i - 2], 0));
 
         const int lo = t - k < 0 ? 0 : t - k;
         const void *tbl[kMaxFrames];
-        for (int f = lo; f <= need; ++f) tbl[f - lo] = dring.p[f % ring];
-        mid_pixel *o = (mid_pixel *)dout.p[t & 1];
-        MID_HIP(hipEventRecord(c0.ev[t], ctx->compute));
+        for (int f = lo; f <= need; ++f) tbl[f - lo] = slot(f);
+        mid_pixel *o = (mid_pixel *)dout.p[i & 1];
+        MID_HIP(hipEventRecord(c0.ev[i], ctx->compute));
         if (int rc = mid_nlm_temporal(ctx, p, tbl, need - lo + 1, k, t - lo, 1, &o, ctx->compute)) return rc;
-        MID_HIP(hipEventRecord(c1.ev[t], ctx->compute));
+        MID_HIP(hipEventRecord(c1.ev[i], ctx->compute));
 
         while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }
 
-        MID_HIP(hipStreamWaitEvent(ctx->download, c1.ev[t], 0));
-        MID_HIP(hipEventRecord(d0.ev[t], ctx->download));
-        MID_HIP(hipMemcpyAsync(host_out[t], dout.p[t & 1], out_bytes, hipMemcpyDeviceToHost, ctx->download));
-        MID_HIP(hipEventRecord(d1.ev[t], ctx->download));
+        MID_HIP(hipStreamWaitEvent(ctx->download, c1.ev[i], 0));
+        MID_HIP(hipEventRecord(d0.ev[i], ctx->download));
+        MID_HIP(hipMemcpyAsync(host_out[i], dout.p[i & 1], out_bytes, hipMemcpyDeviceToHost, ctx->download));
+        MID_HIP(hipEventRecord(d1.ev[i], ctx->download));
 
         if (!overlap) {   // the reference's behaviour: a fence wait after every submit (src/main.cpp:1092)
             MID_HIP(hipStreamSynchronize(ctx->upload));
@@ -122,22 +133,21 @@ extern "C" int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const voi
     MID_HIP(hipStreamSynchronize(ctx->download));
     const auto wall1 = std::chrono::steady_clock::now();
 
-    if (getenv("MID_PIPE_TRACE")) {   // development aid: per-frame stream timeline relative to upload(0)
-        for (int t = 0; t < n; ++t) {
-            float u0, u1, k0, k1, e0, e1;
-            (void)hipEventElapsedTime(&u0, up0.ev[0], up0.ev[t]); (void)hipEventElapsedTime(&u1, up0.ev[0], up1.ev[t]);
-            (void)hipEventElapsedTime(&k0, up0.ev[0], c0.ev[t]);  (void)hipEventElapsedTime(&k1, up0.ev[0], c1.ev[t]);
-            (void)hipEventElapsedTime(&e0, up0.ev[0], d0.ev[t]);  (void)hipEventElapsedTime(&e1, up0.ev[0], d1.ev[t]);
-            fprintf(stderr, "frame %2d  up %.3f-%.3f  compute %.3f-%.3f  down %.3f-%.3f ms\n", t, u0, u1, k0, k1, e0, e1);
+    if (getenv("MID_PIPE_TRACE")) {   // development aid: per-output stream timeline relative to the first upload
+        for (int i = 0; i < count; ++i) {
+            float k0, k1, e0, e1;
+            (void)hipEventElapsedTime(&k0, up0.ev[0], c0.ev[i]);  (void)hipEventElapsedTime(&k1, up0.ev[0], c1.ev[i]);
+            (void)hipEventElapsedTime(&e0, up0.ev[0], d0.ev[i]);  (void)hipEventElapsedTime(&e1, up0.ev[0], d1.ev[i]);
+            fprintf(stderr, "output %2d  compute %.3f-%.3f  down %.3f-%.3f ms\n", first + i, k0, k1, e0, e1);
         }
     }
     if (timings_ms) {
         float kern = 0.f, copy = 0.f, ms = 0.f;
-        for (int t = 0; t < n; ++t) {
-            MID_HIP(hipEventElapsedTime(&ms, c0.ev[t], c1.ev[t])); kern += ms;
-            MID_HIP(hipEventElapsedTime(&ms, up0.ev[t], up1.ev[t])); copy += ms;
-            MID_HIP(hipEventElapsedTime(&ms, d0.ev[t], d1.ev[t])); copy += ms;
+        for (int i = 0; i < count; ++i) {
+            MID_HIP(hipEventElapsedTime(&ms, c0.ev[i], c1.ev[i])); kern += ms;
+            MID_HIP(hipEventElapsedTime(&ms, d0.ev[i], d1.ev[i])); copy += ms;
         }
+        for (int i = 0; i < n_up; ++i) { MID_HIP(hipEventElapsedTime(&ms, up0.ev[i], up1.ev[i])); copy += ms; }
         timings_ms[0] = std::chrono::duration<float, std::milli>(wall1 - wall0).count();
         timings_ms[1] = kern;
         timings_ms[2] = copy;
@@ -145,6 +155,11 @@ extern "C" int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const voi
     return MID_OK;
 }
 
+extern "C" int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
+                                int n, int k, mid_pixel *const *host_out, int overlap, float *timings_ms)
+{
+    return mid_sequence_nlm_range(ctx, p, host_frames, n, k, 0, n, host_out, overlap, timings_ms);
+}
 
 // The reference's own multi-frame mode: target fixed, neighbours streamed (see mi_denoise.h).
 extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const void *host_target,

@@ -168,6 +168,11 @@ int mid_pack_u8(mid_ctx *ctx, const float *in, size_t n_values, uint8_t *out, vo
  * timings_ms (optional, 3 floats): total wall, sum of kernel time, sum of copy time. */
 int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
                      int n_frames, int k, mid_pixel *const *host_out, int overlap, float *timings_ms);
+/* Same, for the output frames [first, first+count) only (host_out has `count` entries): the unit of
+ * frame-block sharding -- a device filters its block and uploads the k halo frames on either side. */
+int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
+                           int n_frames, int k, int first, int count, mid_pixel *const *host_out,
+                           int overlap, float *timings_ms);
 
 /* The reference's literal multi-frame mode (src/main.cpp:1539-1606): ONE target, its neighbour frames
  * streamed from the host.  W = sum over frames of one nonlocal.comp dispatch each (target fixed), then

@@ -136,3 +136,33 @@ def test_gpu_temporal_window_option(tmp_path):
     got = mid.load_image(tmp_path / "output-nonlinear-nlm-multiframe.exr")
     ref = oracle.nlm_temporal(frames, k=1, first=2, count=1, search=(-10, 11), patch=(-3, 4))[0]
     assert rel_err(got, ref) < 2e-5
+
+
+@pytest.mark.gpu
+def test_animation_mode(tmp_path):
+    """--animation: every frame filtered with temporal NLM, frame blocks over devices (1 here; --gpus 3 on a
+    1-GPU box must fail loudly, not fall back)."""
+    d, frames, _, ext = _make_animation(tmp_path, True, n=6)
+    out = tmp_path / "o"
+    out.mkdir()
+    r = _run([str(d / "Animation01_X_0000.exr"), "--animation", "--temporal-k", "2", "--outdir", str(out)], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = oracle.nlm_temporal(frames, k=2)
+    for i in range(6):
+        got = mid.load_image(out / f"output-animation-Animation01_X_{i:04d}.exr")
+        assert rel_err(got, ref[i]) < 2e-5, i
+    import torch
+    if torch.cuda.device_count() == 1:
+        r = _run([str(d / "Animation01_X_0000.exr"), "--animation", "--gpus", "3", "--outdir", str(out)], tmp_path)
+        assert r.returncode == 1 and "device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sequence_range_blocks_equal_whole(ctx):
+    """mid_sequence_nlm_range over blocks == the whole sequence (the unit of frame-block sharding)."""
+    rng = np.random.default_rng(5)
+    frames = [rng.random((24, 40, 4), dtype=np.float32) for _ in range(9)]
+    whole, _ = ctx.sequence_nlm(frames, k=2)
+    for start, count in ((0, 3), (3, 3), (6, 3), (0, 1), (4, 5), (8, 1)):
+        part, _ = ctx.sequence_nlm(frames, k=2, first=start, count=count)
+        assert all(np.array_equal(part[i], whole[start + i]) for i in range(count)), (start, count)

@@ -308,10 +308,9 @@ static int dispatch_radius(mid_ctx *ctx, int radius, BilArgs &a, hipStream_t s)
     switch (radius) {
     case 4:  return launch_tiled<4, 2, 8, FMT, LINEAR, MODE>(ctx, a, s);    // BASELINE config 1 window
     case 8:  return launch_tiled<8, 2, 8, FMT, LINEAR, MODE>(ctx, a, s);    // BASELINE configs 2 and 4
-    case 10: return launch_tiled<10, 2, 8, FMT, LINEAR, MODE>(ctx, a, s);   // CPU path window, src/main.cpp:1819
+    case 10: return launch_tiled<10, 2, 16, FMT, LINEAR, MODE>(ctx, a, s);  // CPU path window, src/main.cpp:1819
     case 20:                                                                 // TEXEL_WINDOW as shipped
-        if (MODE == 0) return launch_tiled<20, 1, 16, FMT, LINEAR, MODE>(ctx, a, s);
-        return launch_tiled<20, 1, 8, FMT, LINEAR, MODE>(ctx, a, s);          // two tiles (image + guide) must fit 160 KB
+        return launch_tiled<20, 1, 8, FMT, LINEAR, MODE>(ctx, a, s);          // 80 KB tile: two workgroups per CU (or image + guide tile)
     default: break;
     }
     {   // run-time radius, LDS tiled

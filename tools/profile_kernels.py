@@ -30,5 +30,17 @@ for lay in (0, 1):
         ctx.bilateral_dev(fp[0], op[0], W, H, 8, 2.0, 0.2, lay, 0, s)
 for _ in range(reps):
     ctx.bilateral_dev(fp[0], op[0], W, H, 20, 2.0, 0.2, 0, 0, s)
+import ctypes
+lay = [(f[..., :4].clamp(0, 1) * 255).to(torch.uint8).contiguous() for f in frames[:4]]
+tbl = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in lay])
+bp = mid.BilateralParams(W, H, 2.0, 0.2, 8, 0, 0)
+wbuf = torch.rand((H, W, 8), device=dev) + 0.5
+u8 = torch.empty((H, W, 4), device=dev, dtype=torch.uint8)
+zp = mid.NormalizeParams(W, H)
+for _ in range(reps):
+    mid.lib.mid_bilateral_layers(ctx.handle, ctypes.byref(bp), fp[0], tbl, 4, op[0], s)
+    mid.lib.mid_normalize(ctx.handle, ctypes.byref(zp), wbuf.data_ptr(), op[1], s)
+    mid.lib.mid_pack_u8(ctx.handle, op[1], W * H * 4, u8.data_ptr(), s)
+    mid.lib.mid_unpack_u8(ctx.handle, u8.data_ptr(), W * H * 4, 0, op[2], s)
 torch.cuda.synchronize()
 print("done")

@@ -23,7 +23,7 @@ def short(name):
 
 
 # ---- kernel stats ----------------------------------------------------------------------------
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     ours = [r for r in rows if "mid::" in r["Name"]]
@@ -35,7 +35,7 @@ if stats:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                         r["MinNs"], r["MaxNs"], r["StdDev"]])
     # per-dispatch durations of the dominant kernel by grid size (8-frame launches vs 1-frame ones)
-    tr = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+    tr = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")), key=os.path.getmtime, reverse=True)
     by = defaultdict(list)
     for r in csv.DictReader(open(tr[0])):
         if "mid::" in r["Kernel_Name"]:
@@ -49,7 +49,12 @@ if stats:
 
 # ---- PMC -------------------------------------------------------------------------------------
 pmc = defaultdict(lambda: defaultdict(list))
+newest = {}
 for path in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    d_ = os.path.dirname(os.path.dirname(path))
+    if d_ not in newest or os.path.getmtime(path) > os.path.getmtime(newest[d_]):
+        newest[d_] = path
+for path in newest.values():
     seen = defaultdict(float)
     for r in csv.DictReader(open(path)):
         if "mid::" not in r["Kernel_Name"]:

@@ -160,7 +160,13 @@ def main():
     import image_denoising_filter_amd as mid
     from image_denoising_filter_amd import sharding
     ctx = mid.Context(local_rank)
-    stream = torch.cuda.current_stream().cuda_stream     # kernels and hipEvents go on torch's current stream
+    # One explicit (non-default) stream for everything: torch ops, RCCL waits (req.wait() orders the CURRENT
+    # torch stream), the library's kernels and the hipEvents that time them.  The default stream's handle is
+    # 0, which the C-ABI reads as "use the context's own stream" -- that would not be ordered after RCCL.
+    tstream = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     def barrier():
         if world > 1:

@@ -5,7 +5,7 @@ import sys, os; sys.path.insert(0, os.getcwd())
 import torch, image_denoising_filter_amd as mid, bench
 torch.cuda.set_device(0); ctx = mid.Context(0); dev = torch.device("cuda", 0)
 frames = bench.synth_frames(2, 100, dev); out = torch.empty((bench.H, bench.W, 4), device=dev)
-s = torch.cuda.current_stream().cuda_stream
+ts = torch.cuda.Stream(); torch.cuda.set_stream(ts); s = ts.cuda_stream
 def run(n, R, lay):
     tm = bench.Timers(mid, ctx, 1); tm.tick(0, s)
     for _ in range(n): ctx.bilateral_dev(frames[0].data_ptr(), out.data_ptr(), bench.W, bench.H, R, 2.0, 0.2, lay, 0, s)

@@ -7,7 +7,7 @@ torch.cuda.set_device(0); ctx = mid.Context(0); dev = torch.device("cuda", 0)
 F = 8
 frames = bench.synth_frames(F, 100, dev); outs = [torch.empty((bench.H, bench.W, 4), device=dev) for _ in range(F)]
 fp, op = [f.data_ptr() for f in frames], [o.data_ptr() for o in outs]
-s = torch.cuda.current_stream().cuda_stream
+ts = torch.cuda.Stream(); torch.cuda.set_stream(ts); s = ts.cuda_stream
 def run(n, nf):
     tm = bench.Timers(mid, ctx, 1); tm.tick(0, s)
     for _ in range(n): ctx.nlm_temporal_dev(fp[:nf], op[:nf], bench.W, bench.H, 0.5, (-10, 11), (-3, 4), 0, 0, nf, 0, s)

@@ -16,7 +16,7 @@ F = 8
 frames = bench.synth_frames(F, 100, dev)
 outs = [torch.empty((bench.H, bench.W, 4), device=dev) for _ in range(F)]
 fp, op = [f.data_ptr() for f in frames], [o.data_ptr() for o in outs]
-s = torch.cuda.current_stream().cuda_stream
+ts = torch.cuda.Stream(); torch.cuda.set_stream(ts); s = ts.cuda_stream
 W, H = bench.W, bench.H
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for _ in range(reps):

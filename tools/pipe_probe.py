@@ -1,11 +1,20 @@
+import os, sys, subprocess
+code = r'''
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+import numpy as np
 import image_denoising_filter_amd as mid
 ctx = mid.Context(0)
 rng = np.random.default_rng(0)
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n = 16
 frames = [(rng.random((1080, 1920, 4), dtype=np.float32) * 4).astype(np.float32) for _ in range(n)]
-for ov in (True, False, True):
-    outs, (wall, kern, copy) = ctx.sequence_nlm(frames, k=0, overlap=ov, **mid.NLM_BENCH)
-    print(f"overlap={ov} n={n}: wall {wall:.2f} ms  kernel {kern:.2f}  copy {copy:.2f}  -> {n*1920*1080/wall/1e3:.0f} Mpx/s", flush=True)
+ctx.sequence_nlm(frames[:2], k=0, **mid.NLM_BENCH)
+for k in (0, 2):
+    for ov in (True, False):
+        outs, (wall, kern, copy) = ctx.sequence_nlm(frames, k=k, overlap=ov, **mid.NLM_BENCH)
+        print(f"batch={os.environ.get('MID_PIPE_BATCH','auto')} k={k} overlap={ov}: wall {wall:.2f} ms kernel {kern:.2f} copy {copy:.2f} -> {n*1920*1080/wall/1e3:.0f} Mpx/s", flush=True)
+'''
+for b in sys.argv[1:]:
+    env = dict(os.environ)
+    if b != "auto": env["MID_PIPE_BATCH"] = b
+    subprocess.run([sys.executable, "-c", code], env=env, check=True)

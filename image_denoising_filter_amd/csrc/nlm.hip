@@ -77,17 +77,25 @@ __device__ __forceinline__ float horizontal_box(float v)
     return c;
 }
 
-// XCD-aware bijective remap of the flat workgroup id: workgroups are dealt round-robin over
-// the 8 XCDs, so give each XCD one contiguous chunk of tiles (neighbouring tiles share halo
-// texels in that XCD's L2).  Speed only; any placement is correct.
-__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg)
+// XCD-aware remap of a workgroup's tile index INSIDE its frame.  Workgroups are dealt round-robin over
+// the 8 XCDs (XCD = linear id % 8).  Frames stay in launch order -- every XCD gets an equal share of every
+// output frame, which matters because frames at the ends of a sequence have shorter temporal windows
+// (an earlier whole-grid remap gave XCD 0 only 3-neighbour frames and XCD 3 only 5-neighbour ones: 18 %
+// slower) -- and within a frame the tiles an XCD receives are made one contiguous run, so neighbouring
+// tiles share halo texels in that XCD's L2.  Bijective for any tile count; speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_remap_in_frame(unsigned t, unsigned tiles, unsigned frame)
 {
-    const unsigned q = nwg >> 3, r = nwg & 7u, x = bid & 7u, i = bid >> 3;
-    return x * q + (x < r ? x : r) + i;
+    const unsigned off = (frame * tiles) & 7u;          // XCD of this frame's tile 0
+    const unsigned c = (t + off) & 7u;                  // XCD this workgroup runs on
+    unsigned start = 0;                                 // tiles owned by XCDs before c
+    for (unsigned cc = 0; cc < c; ++cc) {
+        const unsigned first = (cc + 8u - off) & 7u;
+        start += first < tiles ? (tiles - first + 7u) >> 3 : 0u;
+    }
+    const unsigned first_c = (c + 8u - off) & 7u;
+    return start + ((t - first_c) >> 3);
 }
 
-// MULTI = more than one neighbour frame per output (temporal window): only then are the
-// per-frame sums kept apart from the running totals (the reference's `+=` into WeightInfo).
 template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 {
@@ -109,9 +117,8 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const unsigned tiles = (unsigned)(a.tiles_x * a.tiles_y);
-    const unsigned flat = xcd_remap(blockIdx.x, gridDim.x);
-    const int fz = (int)(flat / tiles);
-    const unsigned trem = flat - (unsigned)fz * tiles;
+    const int fz = (int)(blockIdx.x / tiles);
+    const unsigned trem = xcd_remap_in_frame(blockIdx.x - (unsigned)fz * tiles, tiles, (unsigned)fz);
     const int ty = (int)(trem / (unsigned)a.tiles_x), tx = (int)(trem - (unsigned)ty * a.tiles_x);
 
     const int w = a.w, h = a.h;
@@ -346,6 +353,7 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
         if (multi) {
             if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, FUSED, 1>(ctx, a, s);
             if (variant == 2) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 1>(ctx, a, s);
+            if (variant == 3) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 7>(ctx, a, s);
             return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3>(ctx, a, s);
         }
         if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, false, 3>(ctx, a, s);

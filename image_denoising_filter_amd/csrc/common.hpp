@@ -99,11 +99,24 @@ template <int FMT, bool LINEAR>
 __device__ __forceinline__ void fill_tile(float4 *lds, int tw, int th, const void *img, int w, int h,
                                           int x0, int y0, int tid, int nthreads)
 {
+    // four texels per thread per trip: the four global loads are in flight together, so a tile costs
+    // about n/(4*nthreads) memory latencies instead of n/nthreads
     const int n = tw * th;
-    for (int t = tid; t < n; t += nthreads) {
-        const int ty = t / tw, tx = t - ty * tw;
-        lds[t] = LINEAR ? fetch_linear<FMT>(img, w, h, x0 + tx, y0 + ty)
-                        : fetch_texture<FMT>(img, w, h, x0 + tx, y0 + ty);
+    for (int t0 = tid; t0 < n; t0 += 4 * nthreads) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + j * nthreads;
+            const int ty = t / tw, tx = t - ty * tw;
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < n) v[j] = LINEAR ? fetch_linear<FMT>(img, w, h, x0 + tx, y0 + ty)
+                                     : fetch_texture<FMT>(img, w, h, x0 + tx, y0 + ty);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + j * nthreads;
+            if (t < n) lds[t] = v[j];
+        }
     }
 }
 

@@ -154,7 +154,8 @@ int mid_normalize(mid_ctx *ctx, const mid_normalize_params *p,
  * unpack flavour 0 = UNORM texel decode c/255 (src/texture.cpp:16, src/main.cpp:341);
  *        flavour 1 = CPU decode (float)c * (1.0f/255.0f) (src/main.cpp:1804-1807).
  * pack = (unsigned char)(255.0f*v), truncation (GetImageFromGPU, src/main.cpp:97-103), clamped
- * to [0,255] only where that cast is undefined in C.  n_values counts channels, not pixels. */
+ * to [0,255] only where that cast is undefined in C.  n_values counts channels, not pixels.
+ * The u8 buffer must be 4-byte aligned and the float buffer 16-byte aligned (hipMalloc'd buffers are). */
 int mid_unpack_u8(mid_ctx *ctx, const uint8_t *in, size_t n_values, int flavour, float *out, void *stream);
 int mid_pack_u8(mid_ctx *ctx, const float *in, size_t n_values, uint8_t *out, void *stream);
 

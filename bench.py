@@ -135,6 +135,67 @@ def cpu_baseline():
                       f"on a 1920x{rows} RGBA32F strip, median of {len(ts)} runs; the reference has no CPU NLM"}
 
 
+class _DryContext:
+    """Stands in for the C-ABI context in --dry-run: records what would be launched, computes nothing."""
+    def __init__(self):
+        self.launches = []
+
+    def nlm_temporal_dev(self, frame_ptrs, out_ptrs, w, h, hparam, search, patch, k, first, count, fmt, stream=None):
+        assert 0 <= first and first + count <= len(frame_ptrs) and len(out_ptrs) == count
+        self.launches.append((len(frame_ptrs), k, first, count))
+
+
+def dry_run(args):
+    """The N-rank control flow of main() on CPU tensors over gloo: process group, barriers, the timed loop,
+    max-over-ranks, the temporal step with its overlapped halo exchange, one JSON line from rank 0."""
+    from image_denoising_filter_amd import sharding
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    h, w, F, k = 12, 20, args.frames, 2
+    g = torch.Generator().manual_seed(100 + rank)
+    frames = [torch.rand((h, w, 4), generator=g) for _ in range(F)]
+    outs = [torch.empty((h, w, 4)) for _ in range(F)]
+    ctx = _DryContext()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.nlm_temporal_dev([f.data_ptr() for f in frames], [o.data_ptr() for o in outs], w, h, HPARAM, SEARCH, PATCH, 0, 0, F, 0)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_seq = world * F
+    start, count = sharding.partition(n_seq, world)[rank]
+    covered = []
+
+    def launch(fr, first, cnt, off):
+        ctx.nlm_temporal_dev([f.data_ptr() for f in fr], [o.data_ptr() for o in outs[off:off + cnt]], w, h, HPARAM, SEARCH, PATCH, k, first, cnt, 0)
+        covered.extend(range(off, off + cnt))
+    have = sharding.temporal_block_overlapped(launch, frames, n_seq, k)
+    assert sorted(covered) == list(range(count)), covered
+    lo, hi = max(0, start - k), min(n_seq - 1, start + count - 1 + k)
+    assert sorted(have) == list(range(lo, hi + 1))
+    if world > 1:
+        # halo frames must be the neighbours' data: every rank seeds its frames with 100 + its rank
+        for f, tns in have.items():
+            owner = f // F
+            ref = torch.rand((h, w, 4), generator=torch.Generator().manual_seed(100 + owner)) if f % F == 0 else None
+            if ref is not None:
+                assert torch.equal(tns, ref), f"frame {f} is not rank {owner}'s data"
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no kernels)", "dry_run": True, "n_gpus": world, "steps": args.steps,
+                          "value": None, "elapsed_s": round(elapsed, 6), "launches_rank0": len(ctx.launches)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,7 +204,12 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the multi-rank control flow (gloo, no kernels, tiny frames); "
+                         "marks its JSON dry_run=true -- never a measurement")
     args = ap.parse_args()
+    if args.dry_run:
+        return dry_run(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

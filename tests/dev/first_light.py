@@ -1,8 +1,8 @@
 """First-light check on the GPU box: every kernel against the oracle on small frames, then
-rough 1080p timings.  Development aid; the real suite is tests/ -m gpu."""
+rough 1080p timings.  Development aid (lives under tests/ because it uses the oracle); the real suite is tests/ -m gpu."""
 import sys, time
 import numpy as np
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 import image_denoising_filter_amd as mid
 

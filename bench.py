@@ -123,7 +123,7 @@ def cpu_baseline():
     # the reference's other choice (1 thread, src/main.cpp:1979) and all host cores, on a thinner strip
     other = {}
     small = img[:60].copy()
-    for th in (1, os.cpu_count() or 1):
+    for th in (1, min(os.cpu_count() or 1, 16)):     # 16 = the CPU share of a one-GPU box
         f2 = (lambda: oracle.ref_cpu_bilateral(small, 10, th)) if kind == "reference" else \
              (lambda: oracle.cpu_bilateral(small, 10, 10.0, 0.2, True, th))
         t0 = time.perf_counter()
@@ -201,7 +201,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--dry-run", action="store_true",

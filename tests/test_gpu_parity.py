@@ -261,3 +261,24 @@ def test_4k_frame_windows(ctx):
             sy, sx = slice(max(ya, 0), min(yb, H4)), slice(max(xa, 0), min(xb, W4))
             c[sy.start - ya:sy.stop - ya, sx.start - xa:sx.stop - xa] = img[sy, sx]
             assert rel_err(out[y0:y0 + 20, x0:x0 + 20], fn(c)[halo:halo + 20, halo:halo + 20]) < NLM_TOL, (y0, x0)
+
+
+# ---- non-finite texels (EXR renders do contain them) -----------------------------------------------
+def test_nan_and_inf_texels_propagate_like_the_oracle(ctx):
+    """A NaN texel poisons exactly the pixels whose windows see it; +inf texels follow IEEE (inf-inf, 0*inf = NaN).
+    The set of non-finite outputs must match the oracle's and the finite ones stay within tolerance."""
+    rng = np.random.default_rng(70)
+    h, w = 60, 100
+    img = (synth_hdr(rng, h, w) * 0.25).astype(np.float32)
+    img[20, 30, 1] = np.nan
+    img[40, 70, 0] = np.inf
+    img[5, 90, 2] = -np.inf
+    img[50, 10, 3] = np.nan                       # alpha only: not part of any distance
+    for name, got, ref in (
+        ("bilateral", ctx.bilateral(img, 8, 2.0, 0.2), oracle.bilateral_texture(img, 8, 2.0, 0.2)),
+        ("nlm", ctx.nlm_temporal([img], k=0, **NLM_CFGS["bench"])[0], oracle.nlm_temporal([img], k=0, **NLM_CFGS["bench"])[0]),
+    ):
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), name
+        assert np.array_equal(np.isinf(got), np.isinf(ref)), name
+        fin = np.isfinite(ref)
+        assert fin.mean() > 0.5 and rel_err(got[fin], ref[fin]) < NLM_TOL, name

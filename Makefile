@@ -19,9 +19,13 @@ $(CLI): $(CSRC)/cli/mi_denoise.cpp include/mi_denoise.h $(LIB)
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz
 
+# per-file extras: the NLM kernels gain 2-6 % from LLVM's max-ILP scheduling strategy (A/B on MI355X: 3074 vs 3011
+# Mpixel/s batched, 2882 vs 2710 single frame); the bilateral kernels lose 8 % with it, so it stays off there.
+EXTRA_nlm.hip := -mllvm -amdgpu-sched-strategy=max-ilp
+
 build/%.o: $(CSRC)/% $(CSRC)/common.hpp $(CSRC)/codec/image_io.hpp include/mi_denoise.h
 	@mkdir -p $(dir $@)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(EXTRA_$(notdir $<)) -c $< -o $@
 
 oracle:
 	$(MAKE) -C oracle

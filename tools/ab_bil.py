@@ -1,4 +1,6 @@
-"""A/B of bilateral tile variants in separate processes (MID_BIL_VARIANT is read once per process)."""
+"""Times the bilateral kernels at r=4/8/10/20.  It was the A/B driver for tile shapes (MID_BIL_VARIANT selected
+template instantiations that were removed once the winners were fixed in dispatch_radius);
+to A/B a new shape, build a second library and point MID_LIB_PATH at it."""
 import os, subprocess, sys
 code = r'''
 import sys, os; sys.path.insert(0, os.getcwd())

@@ -96,7 +96,7 @@ __device__ __forceinline__ unsigned xcd_remap_in_frame(unsigned t, unsigned tile
     return start + ((t - first_c) >> 3);
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool PIPE = false>
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1>
 __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 {
     // SLO == SHI == 0 selects the run-time search range [a.slo, a.shi) (any window, same patch):
@@ -195,27 +195,11 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 
         for (int sy = 0; sy < SW; ++sy) {
             const float4 *rowp = lds + (wv * R + sy) * LW + lane;
-            if constexpr (PIPE) {
-                // two-stage software pipeline over the search columns: the LDS reads of offset
-                // sx+1 are in flight while offset sx is being computed (two register sets A/B)
-                float4 A[DR], B[DR];
-                load(A, rowp);
-                for (int sx = 0; sx + 1 < SW; sx += 2) {
-                    load(B, rowp + sx + 1);
-                    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the arithmetic
-                    compute(A);
-                    if (sx + 2 < SW) load(A, rowp + sx + 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    compute(B);
-                }
-                if (SW & 1) compute(A);
-            } else {
 #pragma unroll U
-                for (int sx = 0; sx < SW; ++sx) {
-                    float4 n[DR];
-                    load(n, rowp + sx);
-                    compute(n);
-                }
+            for (int sx = 0; sx < SW; ++sx) {
+                float4 n[DR];
+                load(n, rowp + sx);
+                compute(n);
             }
         }
 #pragma unroll
@@ -308,7 +292,7 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
     }
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool PIPE = false>
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1>
 static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
 {
     constexpr bool RTS = (SLO == 0 && SHI == 0);
@@ -317,7 +301,7 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
     const int SW = RTS ? a.shi - a.slo : SHI - SLO;
     const int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + SW - 1;
     const size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
-    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, PIPE>;
+    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     if (int rc = ensure_lds(ctx, (const void *)kern, lds_bytes)) return rc;
@@ -352,16 +336,11 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
     if (p->search_lo == -10 && p->search_hi == 11 && p->patch_lo == -3 && p->patch_hi == 4) {   // 21x21 / 7x7 (benchmark)
         if (multi) {
             if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, FUSED, 1>(ctx, a, s);
-            if (variant == 2) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 1>(ctx, a, s);
-            if (variant == 3) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 7>(ctx, a, s);
             return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3>(ctx, a, s);
         }
         if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, false, 3>(ctx, a, s);
         if (variant == 2) return launch_strip<-10, 11, -3, 4, 7, 12, FMT, FUSED, false, 3>(ctx, a, s);
-        if (variant == 3) return launch_strip<-10, 11, -3, 4, 5, 16, FMT, FUSED, false, 3>(ctx, a, s);
-        if (variant == 4) return launch_strip<-10, 11, -3, 4, 7, 4, FMT, FUSED, false, 7>(ctx, a, s);
         if (variant == 5) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s);
-        if (variant == 6) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7>(ctx, a, s);
         if (variant == 8 || small_r) return launch_strip<-10, 11, -3, 4, 6, 4, FMT, FUSED, false, 7>(ctx, a, s);
         return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7>(ctx, a, s);
     }

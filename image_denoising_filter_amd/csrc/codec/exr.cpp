@@ -1,11 +1,11 @@
 // exr.cpp -- minimal scanline OpenEXR codec over zlib (the reference calls tinyexr's LoadEXR /
 // SaveEXR, src/main.cpp:155,1699,1744,1887; tinyexr is an un-vendored submodule, absent here).
 //
-// Read: single-part scanline files, compression NONE / RLE / ZIPS / ZIP, channel types UINT / HALF /
+// Read: single-part scanline files, compression NONE / RLE / ZIPS / ZIP / PIZ (piz.cpp), channel types UINT / HALF /
 // FLOAT, any data window, increasing or decreasing line order.  Channels R,G,B,A are looked up by name
 // (a layer prefix "xxx.R" is accepted when no plain names exist); a missing A reads as 1.0 and a
 // single-channel file is replicated into RGB -- the behaviour of tinyexr's LoadEXR that the reference
-// relies on (README.md:59 "alpha is kept").  Tiled, multi-part, deep and PIZ/PXR24/B44/DWA files are
+// relies on (README.md:59 "alpha is kept").  Tiled, multi-part, deep and PXR24/B44/DWA files are
 // rejected with a message naming the feature.
 // Write: channels A,B,G,R as FLOAT, ZIP blocks of 16 lines (NONE when the image is smaller than
 // 16x16), the attribute set tinyexr's SaveEXR(data, w, h, 4, 0, ...) emits.
@@ -151,7 +151,7 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
     (void)line_order;   // chunks carry their own y; the offset table is indexed by block either way
     if (chans.empty() || !have_dw || compression < 0) { err = "exr: missing channels/dataWindow/compression"; return false; }
     static const char *cname[] = {"NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
-    if (compression > 3) { err = std::string("exr: compression ") + (compression < 10 ? cname[compression] : "?") + " is not supported (NONE/RLE/ZIPS/ZIP only)"; return false; }
+    if (compression > 4) { err = std::string("exr: compression ") + (compression < 10 ? cname[compression] : "?") + " is not supported (NONE/RLE/ZIPS/ZIP/PIZ only)"; return false; }
     const long W = (long)dw[2] - dw[0] + 1, H = (long)dw[3] - dw[1] + 1;
     if (W <= 0 || H <= 0 || W > 65536 || H > 65536) { err = "exr: bad data window"; return false; }
     if ((double)W * H * 2 > (double)file.size() * 1100.0) { err = "exr: data window larger than the file can hold"; return false; }
@@ -180,7 +180,9 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
     int gray_ch = -1;
     if (gray) for (size_t c = 0; c < chans.size(); ++c) if ((int)c != slot[3]) gray_ch = (int)c;
 
-    const int lines_per_block = compression == 3 ? 16 : 1;
+    const int lines_per_block = compression == 3 ? 16 : compression == 4 ? 32 : 1;
+    std::vector<int> chan_words(chans.size());
+    for (size_t c = 0; c < chans.size(); ++c) chan_words[c] = chans[c].type == 1 ? 1 : 2;
     const size_t nblocks = (size_t)((H + lines_per_block - 1) / lines_per_block);
     std::vector<uint64_t> offsets(nblocks);
     for (auto &o : offsets) o = r.u64();
@@ -202,6 +204,10 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
         if ((size_t)size == expect || compression == 0) {
             if ((size_t)size != expect) { err = "exr: raw chunk has the wrong size"; return false; }
             data = c.p;                                      // stored uncompressed
+        } else if (compression == 4) {
+            if (!piz_decode_block(c.p, (size_t)size, (int)W, (int)nl, chan_words, raw, err)) return false;
+            if (raw.size() != expect) { err = "exr: PIZ chunk decodes to the wrong size"; return false; }
+            data = raw.data();
         } else {
             tmp.resize(expect);
             if (compression == 1) {

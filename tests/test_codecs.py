@@ -142,10 +142,14 @@ def _exr(w, h, channels, compression, lines, pixel_bytes, data_window=None, line
     hdr += attr("lineOrder", "lineOrder", bytes([line_order])) + attr("pixelAspectRatio", "float", struct.pack("<f", 1))
     hdr += attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1))
     hdr += b"\0"
-    lpb = 16 if compression == 3 else 1
+    lpb = 16 if compression == 3 else 32 if compression == 4 else 1
     blocks = []
     for y0 in range(0, h, lpb):
         raw = b"".join(lines[y][n] for y in range(y0, min(h, y0 + lpb)) for n, _ in channels)
+        if compression == 4:
+            import piz_encoder
+            blocks.append((dw[1] + y0, piz_encoder.piz_block(lines[y0:min(h, y0 + lpb)], channels, w, use_runs=pixel_bytes != "noruns")))
+            continue
         if compression in (2, 3):
             t = np.frombuffer(raw, np.uint8)
             t = np.concatenate([t[0::2], t[1::2]])
@@ -153,6 +157,8 @@ def _exr(w, h, channels, compression, lines, pixel_bytes, data_window=None, line
             d[1:] = (d[1:] - d[:-1] + 128) & 255
             z = zlib.compress(d.astype(np.uint8).tobytes())
             payload = z if len(z) < len(raw) else raw
+        elif compression == 4:
+            payload = None                      # filled per 32-line block below
         elif compression == 1:
             t = np.frombuffer(raw, np.uint8)
             t = np.concatenate([t[0::2], t[1::2]])
@@ -246,11 +252,11 @@ def test_exr_unsupported_features_are_named(tmp_path):
     mid.save_image(p, a)
     blob = bytearray(p.read_bytes())
     i = blob.index(b"compression\0compression\0") + 24 + 4
-    blob[i] = 4                                               # PIZ
-    (tmp_path / "piz.exr").write_bytes(bytes(blob))
+    blob[i] = 6                                               # B44
+    (tmp_path / "b44.exr").write_bytes(bytes(blob))
     with pytest.raises(mid.MidError) as e:
-        mid.load_image(tmp_path / "piz.exr")
-    assert "PIZ" in str(e.value) and e.value.code == 5
+        mid.load_image(tmp_path / "b44.exr")
+    assert "B44" in str(e.value) and e.value.code == 5
     blob2 = bytearray(p.read_bytes())
     blob2[5] |= 0x02                                          # tiled bit
     (tmp_path / "tiled.exr").write_bytes(bytes(blob2))
@@ -295,7 +301,79 @@ def test_sanitizer_sweep(tmp_path):
     exe = tmp_path / "codec_sanitize"
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                     os.path.join(ROOT, "tools", "codec_sanitize.cpp"), os.path.join(codec, "png.cpp"), os.path.join(codec, "exr.cpp"),
-                    "-lz", "-o", str(exe)], check=True)
-    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+                    os.path.join(codec, "piz.cpp"), "-lz", "-o", str(exe)], check=True)
+    # two PIZ files from the test encoder (14-bit and 16-bit wavelet modes) join the sweep
+    extra = []
+    rng = np.random.default_rng(0)
+    for name, px in (("s14.exr", (np.round(rng.random((40, 21, 4)) * 16) / 8).astype(np.float16)),
+                     ("s16.exr", (np.round(rng.random((35, 17, 4)) * 4000) * 8).astype(np.float32))):
+        chans = [("A", 1 if px.dtype == np.float16 else 2), ("B", 1 if px.dtype == np.float16 else 2),
+                 ("G", 1 if px.dtype == np.float16 else 2), ("R", 1 if px.dtype == np.float16 else 2)]
+        idx = {"R": 0, "G": 1, "B": 2, "A": 3}
+        lines = [{n: np.ascontiguousarray(px[y, :, idx[n]]).tobytes() for n, _ in chans} for y in range(px.shape[0])]
+        f = tmp_path / name
+        f.write_bytes(_exr(px.shape[1], px.shape[0], chans, 4, lines, None))
+        extra.append(str(f))
+    r = subprocess.run([str(exe)] + extra, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "sanitizer sweep done" in r.stdout
+
+
+# ---- PIZ (decoder checked against the independent test encoder tests/piz_encoder.py) --------------
+@pytest.mark.parametrize("ptype", [1, 2])
+@pytest.mark.parametrize("shape,kind", [((37, 21), "smooth"), ((64, 33), "smooth"), ((5, 70), "noise"), ((33, 1), "smooth"),
+                                        ((40, 48), "flat"), ((35, 19), "wide")])
+def test_exr_piz_reader(tmp_path, ptype, shape, kind):
+    """HALF and FLOAT channels, odd sizes, several 32-line blocks; 'smooth'/'flat' keep the value LUT below
+    2^14 (14-bit wavelet) and produce long runs (run-length symbol), 'wide'/'noise' force the 16-bit wavelet
+    and long Huffman codes."""
+    rng = np.random.default_rng(shape[0] * 7 + shape[1] + ptype)
+    h, w = shape
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == "smooth":
+        px = np.stack([np.round(xx * 0.25) / 4, np.round(yy * 0.5) / 8, np.round((xx + yy) * 0.125) / 2, np.ones((h, w))], -1)
+    elif kind == "flat":
+        px = np.tile(np.float64([0.5, 0.25, 0.125, 1.0]), (h, w, 1))
+    elif kind == "wide":
+        px = rng.random((h, w, 4)) * 60000 - 30000
+    else:
+        px = rng.standard_normal((h, w, 4)) * 3
+    px = px.astype(np.float16 if ptype == 1 else np.float32)
+    chans = [("A", ptype), ("B", ptype), ("G", ptype), ("R", ptype)]
+    idx = {"R": 0, "G": 1, "B": 2, "A": 3}
+    lines = [{n: np.ascontiguousarray(px[y, :, idx[n]]).tobytes() for n, _ in chans} for y in range(h)]
+    for runs in (None, "noruns"):
+        p = tmp_path / f"piz_{runs}.exr"
+        p.write_bytes(_exr(w, h, chans, 4, lines, runs))
+        got = mid.load_image(p)
+        assert np.array_equal(got.view(np.uint32), px.astype(np.float32).view(np.uint32)), (kind, runs)
+
+
+def test_exr_piz_mixed_channel_types_and_corruption(tmp_path):
+    rng = np.random.default_rng(3)
+    h, w = 45, 23
+    r = (np.round(rng.random((h, w)) * 16) / 8).astype(np.float16)       # few distinct values: PIZ really compresses
+    g = (np.round(rng.random((h, w)) * 16) / 8).astype(np.float32)
+    b = np.round(rng.random((h, w)) * 8).astype(np.float16)
+    chans = [("B", 1), ("G", 2), ("R", 1)]
+    lines = [{"R": r[y].tobytes(), "G": g[y].tobytes(), "B": b[y].tobytes()} for y in range(h)]
+    p = tmp_path / "mixed.exr"
+    blob = _exr(w, h, chans, 4, lines, None)
+    p.write_bytes(blob)
+    got = mid.load_image(p)
+    assert np.array_equal(got[..., 0], r.astype(np.float32)) and np.array_equal(got[..., 1], g)
+    assert np.array_equal(got[..., 2], b.astype(np.float32)) and np.all(got[..., 3] == 1)
+    q = tmp_path / "bad.exr"
+    ok = bad = 0
+    for i in range(len(blob) - 600, len(blob), 7):            # corrupt the compressed payload: error or same shape, never a crash
+        bb = bytearray(blob)
+        bb[i] ^= 0xa5
+        q.write_bytes(bytes(bb))
+        try:
+            out = mid.load_image(q)
+            assert out.shape == (h, w, 4)
+            ok += 1
+        except mid.MidError as e:
+            assert e.code == 5
+            bad += 1
+    assert bad > 0

@@ -10,10 +10,42 @@
 
 using namespace mid::codec;
 
-int main()
+static bool sweep_file(const std::vector<uint8_t> &good, bool is_exr, std::mt19937 &rng, long &decoded, long &rejected)
+{
+    auto decode = [&](const std::vector<uint8_t> &f) {
+        int ww, hh;
+        std::string e;
+        bool ok;
+        if (is_exr) { std::vector<float> o; ok = exr_decode(f, ww, hh, o, e); }
+        else { std::vector<uint8_t> o; ok = png_decode(f, ww, hh, o, e); }
+        ok ? ++decoded : ++rejected;
+        return ok;
+    };
+    if (!decode(good)) { printf("valid file rejected\n"); return false; }
+    for (size_t n = 0; n < good.size(); n += (n < 512 ? 1 : 61)) {
+        std::vector<uint8_t> cut(good.begin(), good.begin() + n);
+        if (decode(cut)) { printf("truncated file accepted (%zu of %zu)\n", n, good.size()); return false; }
+    }
+    for (int i = 0; i < 3000; ++i) {
+        std::vector<uint8_t> bad = good;
+        const int nflip = 1 + rng() % 3;
+        for (int k = 0; k < nflip; ++k) bad[rng() % bad.size()] ^= (uint8_t)(1 + rng() % 255);
+        decode(bad);
+    }
+    return true;
+}
+
+int main(int argc, char **argv)
 {
     std::mt19937 rng(1234);
     long decoded = 0, rejected = 0;
+    for (int a = 1; a < argc; ++a) {          // extra files (e.g. PIZ-compressed EXRs written by the tests)
+        std::vector<uint8_t> f;
+        std::string err;
+        if (!read_file(argv[a], f, err)) { printf("%s\n", err.c_str()); return 1; }
+        const std::string name = argv[a];
+        if (!sweep_file(f, name.size() > 4 && name.substr(name.size() - 4) == ".exr", rng, decoded, rejected)) return 1;
+    }
     for (int trial = 0; trial < 6; ++trial) {
         const int w = 1 + rng() % 40, h = 1 + rng() % 40;
         std::vector<uint8_t> px8((size_t)w * h * 4);

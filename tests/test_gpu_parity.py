@@ -282,3 +282,42 @@ def test_nan_and_inf_texels_propagate_like_the_oracle(ctx):
         assert np.array_equal(np.isinf(got), np.isinf(ref)), name
         fin = np.isfinite(ref)
         assert fin.mean() > 0.5 and rel_err(got[fin], ref[fin]) < NLM_TOL, name
+
+
+# ---- degenerate and very large frames ---------------------------------------------------------------
+def test_empty_frames_are_rejected(ctx):
+    """A 0-pixel frame is an argument error (code 1), for every operator."""
+    import ctypes
+    d = ctx.alloc(64)
+    for w_, h_ in ((0, 8), (8, 0), (0, 0), (-3, 4)):
+        bp = mid.BilateralParams(w_, h_, 2.0, 0.2, 4, 0, 0)
+        npar = mid.NlmParams(w_, h_, 0.5, -7, 7, -3, 3, 0)
+        zp = mid.NormalizeParams(w_, h_)
+        assert mid.lib.mid_bilateral(ctx.handle, ctypes.byref(bp), d.ptr, ctx.alloc(64).ptr, None) == 1
+        assert mid.lib.mid_nlm_accum(ctx.handle, ctypes.byref(npar), d.ptr, d.ptr, d.ptr, None) == 1
+        assert mid.lib.mid_normalize(ctx.handle, ctypes.byref(zp), d.ptr, d.ptr, None) == 1
+    assert mid.lib.mid_pack_u8(ctx.handle, d.ptr, 0, d.ptr, None) == 0          # zero values: nothing to do, not an error
+
+
+def test_frame_larger_than_2_gib(ctx):
+    """16384 x 8704 RGBA32F = 2.28 GB per buffer: byte offsets pass 2^31, pixel indices stay in int range.
+    Bilateral r=4 (tuned tile) checked on windows at the far corner; pack/unpack over the whole buffer."""
+    H5, W5 = 8704, 16384
+    rng = np.random.default_rng(80)
+    base = rng.random((256, 512, 4), dtype=np.float32)
+    img = np.tile(base, (H5 // 256, W5 // 512, 1))
+    img[-64:, -64:] = rng.random((64, 64, 4), dtype=np.float32) * 2
+    d_in, d_out = ctx.upload(img), ctx.alloc(img.nbytes)
+    ctx.bilateral_dev(d_in.ptr, d_out.ptr, W5, H5, 4, 2.0, 0.2, mid.LAYOUT_TEXTURE, mid.FMT_RGBA32F)
+    out = ctx.download(d_out, (H5, W5, 4), np.float32)
+    for y0, x0 in ((H5 - 24, W5 - 24), (H5 - 24, 0), (4000, W5 - 24), (0, 0)):
+        ya, yb, xa, xb = y0 - 4, y0 + 28, x0 - 4, x0 + 28
+        c = np.zeros((32, 32, 4), np.float32)
+        sy, sx = slice(max(ya, 0), min(yb, H5)), slice(max(xa, 0), min(xb, W5))
+        c[sy.start - ya:sy.stop - ya, sx.start - xa:sx.stop - xa] = img[sy, sx]
+        assert rel_err(out[y0:y0 + 24, x0:x0 + 24], oracle.bilateral_texture(c, 4, 2.0, 0.2)[4:28, 4:28]) < BIL_TOL, (y0, x0)
+    import ctypes
+    d_u8 = ctx.alloc(H5 * W5 * 4)
+    assert mid.lib.mid_pack_u8(ctx.handle, d_in.ptr, H5 * W5 * 4, d_u8.ptr, None) == 0
+    u8 = ctx.download(d_u8, (H5, W5, 4), np.uint8)
+    assert np.array_equal(u8[-300:], oracle.pack_u8(img[-300:])) and np.array_equal(u8[:300], oracle.pack_u8(img[:300]))

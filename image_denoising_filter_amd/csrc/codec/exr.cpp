@@ -190,8 +190,11 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
 
     rgba.assign((size_t)W * H * 4, 0.f);
     for (size_t i = 0; i < (size_t)W * H; ++i) rgba[i * 4 + 3] = 1.0f;     // missing alpha = 1
-    std::vector<uint8_t> tmp, raw;
-    for (size_t b = 0; b < nblocks; ++b) {
+    std::vector<std::string> errs(nblocks);
+    parallel_for(nblocks, [&](size_t b) {
+        std::string &err = errs[b];
+        auto work = [&]() -> bool {
+        std::vector<uint8_t> tmp, raw;
         if (offsets[b] + 8 > file.size()) { err = "exr: chunk offset beyond end of file"; return false; }
         Reader c{file.data() + offsets[b], file.data() + file.size()};
         const int32_t y = c.i32(), size = c.i32();
@@ -236,7 +239,11 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
             else for (int k = 0; k < 3; ++k) if (slot[k] >= 0) read_ch(slot[k], k, k);
             if (slot[3] >= 0) read_ch(slot[3], 3, 3);
         }
-    }
+            return true;
+        };
+        try { (void)work(); } catch (const std::exception &e) { err = std::string("exr: ") + e.what(); }
+    });
+    for (auto &e : errs) if (!e.empty()) { err = e; return false; }
     w = (int)W; h = (int)H;
     return true;
 }
@@ -282,38 +289,44 @@ bool exr_encode(const float *rgba, int w, int h, std::vector<uint8_t> &file, std
     const size_t table = file.size();
     file.resize(table + nblocks * 8);
     const size_t line_bytes = (size_t)w * 16;
-    std::vector<uint8_t> raw, t, z;
     static const int order[4] = {3, 2, 1, 0};   // A, B, G, R from RGBA
-    for (size_t b = 0; b < nblocks; ++b) {
-        const int y0 = (int)b * lpb, nl = std::min(lpb, h - y0);
-        raw.resize(line_bytes * nl);
-        for (int l = 0; l < nl; ++l)
-            for (int c = 0; c < 4; ++c) {
-                float *dst = (float *)(raw.data() + (size_t)l * line_bytes + (size_t)c * w * 4);
-                const float *src = rgba + (size_t)(y0 + l) * w * 4 + order[c];
-                for (int x = 0; x < w; ++x) dst[x] = src[(size_t)x * 4];
+    std::vector<std::vector<uint8_t>> payload(nblocks);
+    std::vector<std::string> errs(nblocks);
+    parallel_for(nblocks, [&](size_t b) {
+        try {
+            std::vector<uint8_t> raw, t, z;
+            const int y0 = (int)b * lpb, nl = std::min(lpb, h - y0);
+            raw.resize(line_bytes * nl);
+            for (int l = 0; l < nl; ++l)
+                for (int c = 0; c < 4; ++c) {
+                    float *dst = (float *)(raw.data() + (size_t)l * line_bytes + (size_t)c * w * 4);
+                    const float *src = rgba + (size_t)(y0 + l) * w * 4 + order[c];
+                    for (int x = 0; x < w; ++x) dst[x] = src[(size_t)x * 4];
+                }
+            if (zip) {
+                const size_t n = raw.size(), half = (n + 1) / 2;
+                t.resize(n);
+                for (size_t i = 0, a = 0, bb = half; i < n;) {   // even bytes first, odd bytes second
+                    t[a++] = raw[i++];
+                    if (i < n) t[bb++] = raw[i++];
+                }
+                uint8_t prev = t[0];
+                for (size_t i = 1; i < n; ++i) { const uint8_t cur = t[i]; t[i] = (uint8_t)(cur - prev + 128); prev = cur; }
+                uLongf clen = compressBound((uLong)n);
+                z.resize(clen);
+                if (compress2(z.data(), &clen, t.data(), (uLong)n, 6) != Z_OK) { errs[b] = "exr: zlib compress failed"; return; }
+                if (clen < n) { z.resize(clen); payload[b].swap(z); return; }   // otherwise stored raw, as the format prescribes
             }
+            payload[b].swap(raw);
+        } catch (const std::exception &e) { errs[b] = std::string("exr: ") + e.what(); }
+    });
+    for (auto &e : errs) if (!e.empty()) { err = e; return false; }
+    for (size_t b = 0; b < nblocks; ++b) {
         const uint64_t off = file.size();
         memcpy(file.data() + table + b * 8, &off, 8);
-        put_i32(file, y0);
-        const uint8_t *payload = raw.data();
-        size_t plen = raw.size();
-        if (zip) {
-            const size_t n = raw.size(), half = (n + 1) / 2;
-            t.resize(n);
-            for (size_t i = 0, a = 0, bb = half; i < n;) {   // even bytes first, odd bytes second
-                t[a++] = raw[i++];
-                if (i < n) t[bb++] = raw[i++];
-            }
-            uint8_t prev = t[0];
-            for (size_t i = 1; i < n; ++i) { const uint8_t cur = t[i]; t[i] = (uint8_t)(cur - prev + 128); prev = cur; }
-            uLongf clen = compressBound((uLong)n);
-            z.resize(clen);
-            if (compress2(z.data(), &clen, t.data(), (uLong)n, 6) != Z_OK) { err = "exr: zlib compress failed"; return false; }
-            if (clen < n) { payload = z.data(); plen = clen; }   // otherwise stored raw, as the format prescribes
-        }
-        put_i32(file, (int32_t)plen);
-        put_bytes(file, payload, plen);
+        put_i32(file, (int32_t)b * lpb);
+        put_i32(file, (int32_t)payload[b].size());
+        put_bytes(file, payload[b].data(), payload[b].size());
     }
     return true;
 }

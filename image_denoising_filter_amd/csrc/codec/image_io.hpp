@@ -5,8 +5,26 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <thread>
+
 namespace mid {
 namespace codec {
+
+// Blocks of an image file are independent: run fn(i) for i in [0,n) on up to 16 host threads.
+inline void parallel_for(size_t n, const std::function<void(size_t)> &fn)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 4, 16), n);
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t)
+        th.emplace_back([&] { for (size_t i = next++; i < n; i = next++) fn(i); });
+    for (auto &t : th) t.join();
+}
 
 bool png_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<uint8_t> &rgba, std::string &err);
 bool png_encode(const uint8_t *rgba, int w, int h, std::vector<uint8_t> &file, std::string &err);

@@ -202,6 +202,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--workload", choices=["nlm", "bilateral"], default="nlm",
+                    help="what the timed region measures: nlm = BASELINE configs[2] (the north_star target, default); "
+                         "bilateral = configs[1], r=8, linear-buffer layout, one launch per frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
@@ -243,8 +246,23 @@ def main():
     outs = [torch.empty((H, W, 4), device=device, dtype=torch.float32) for _ in range(F)]
     fptr, optr = [f.data_ptr() for f in frames], [o.data_ptr() for o in outs]
 
-    def step():
-        ctx.nlm_temporal_dev(fptr, optr, W, H, HPARAM, SEARCH, PATCH, 0, 0, F, mid.FMT_RGBA32F, stream)
+    if args.workload == "nlm":
+        def step():
+            ctx.nlm_temporal_dev(fptr, optr, W, H, HPARAM, SEARCH, PATCH, 0, 0, F, mid.FMT_RGBA32F, stream)
+        flop_px, bytes_px, launches_per_step = NLM_FLOP_PER_PX, NLM_BYTES_PER_PX, 1
+        metric = "Mpixel/s (NLM 21x21 search / 7x7 patch, 1920x1080 RGBA32F)"
+        workload = "nlm_21x21_7x7_1080p_hdr (BASELINE configs[2]; single-frame NLM, fused accumulate+normalize)"
+        kernel = "nlm_strip_kernel<-10,11,-3,4,8,4,f32,FUSED>"
+        flop_note = "14,112/px (minimum-work separable NLM, SURVEY.md 8d)"
+    else:
+        def step():
+            for i in range(F):
+                ctx.bilateral_dev(fptr[i], optr[i], W, H, 8, 2.0, 0.2, mid.LAYOUT_LINEAR, mid.FMT_RGBA32F, stream)
+        flop_px, bytes_px, launches_per_step = BIL_FLOP_PER_PX, BIL_BYTES_PER_PX, F
+        metric = "Mpixel/s (bilateral r=8, 1920x1080 RGBA32F)"
+        workload = "bilateral_r8_linear_1080p_hdr (BASELINE configs[1]; one launch per frame)"
+        kernel = "bilateral_kernel<8,2,8,f32,LINEAR>"
+        flop_note = "5,780/px (20 flop per tap x 17x17 taps, SURVEY.md 8d)"
 
     for _ in range(args.warmup):
         step()
@@ -267,27 +285,28 @@ def main():
     avg_launch_s = sum(kernel_ms) / len(kernel_ms) / 1e3
 
     value = world * F * args.steps * NPIX / 1e6 / elapsed
-    px_per_launch = F * NPIX
+    px_per_launch = F * NPIX // launches_per_step
+    avg_launch_s /= launches_per_step        # the timers bracket one step = launches_per_step back-to-back launches
     res = {
-        "metric": "Mpixel/s (NLM 21x21 search / 7x7 patch, 1920x1080 RGBA32F)",
+        "metric": metric,
         "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "nlm_21x21_7x7_1080p_hdr (BASELINE configs[2]; single-frame NLM, fused accumulate+normalize)",
+        "config": {"workload": workload,
                    "frames_per_gpu_per_step": F, "width": W, "height": H, "h": HPARAM,
                    "parallelism": f"frame-sharded x{world}, no data-path collective"},
         "roofline": {
-            "bound": "mfma", "achieved": round(NLM_FLOP_PER_PX * px_per_launch / avg_launch_s / 1e12, 3),
+            "bound": "mfma", "achieved": round(flop_px * px_per_launch / avg_launch_s / 1e12, 3),
             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(NLM_FLOP_PER_PX * px_per_launch / avg_launch_s / 1e12 / PEAK_FP32_TFLOPS, 4),
-            "traffic": load_traffic(F),
-            "kernel": "nlm_strip_kernel<-10,11,-3,4,8,4,f32,FUSED>", "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+            "frac": round(flop_px * px_per_launch / avg_launch_s / 1e12 / PEAK_FP32_TFLOPS, 4),
+            "traffic": load_traffic(F) if args.workload == "nlm" else None,
+            "kernel": kernel, "avg_launch_ms": round(avg_launch_s * 1e3, 4),
             "note": "compute roofline: the kernel is fp32-VALU bound and issues no MFMA; the peak is the fp32 "
                     "vector peak, which equals the dense f32 MFMA peak on gfx950 (157.3 TFLOP/s). Algorithmic "
-                    "flops = 14,112/px (minimum-work separable NLM, SURVEY.md 8d) x px per launch.",
-            "hbm": {"achieved_GBs": round(NLM_BYTES_PER_PX * px_per_launch / avg_launch_s / 1e9, 1),
+                    f"flops = {flop_note} x px per launch.",
+            "hbm": {"achieved_GBs": round(bytes_px * px_per_launch / avg_launch_s / 1e9, 1),
                     "peak_GBs": PEAK_HBM_GBS,
-                    "frac": round(NLM_BYTES_PER_PX * px_per_launch / avg_launch_s / 1e9 / PEAK_HBM_GBS, 5)},
+                    "frac": round(bytes_px * px_per_launch / avg_launch_s / 1e9 / PEAK_HBM_GBS, 5)},
         },
     }
 

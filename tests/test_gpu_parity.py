@@ -321,3 +321,43 @@ def test_frame_larger_than_2_gib(ctx):
     assert mid.lib.mid_pack_u8(ctx.handle, d_in.ptr, H5 * W5 * 4, d_u8.ptr, None) == 0
     u8 = ctx.download(d_u8, (H5, W5, 4), np.uint8)
     assert np.array_equal(u8[-300:], oracle.pack_u8(img[-300:])) and np.array_equal(u8[:300], oracle.pack_u8(img[:300]))
+
+
+# ---- randomized differential sweep ------------------------------------------------------------------
+def test_random_parameter_sweep_against_oracle(ctx):
+    """40 random (size, format, operator, parameter) draws, every one compared with the oracle."""
+    rng = np.random.default_rng(2025)
+    for case in range(40):
+        h, w = int(rng.integers(1, 90)), int(rng.integers(1, 150))
+        ldr = bool(rng.integers(0, 2))
+        img = synth_ldr(rng, h, w) if ldr else (synth_hdr(rng, h, w) * float(rng.uniform(0.1, 1.0))).astype(np.float32)
+        f32 = oracle.unpack_u8(img, 0) if ldr else img
+        op = int(rng.integers(0, 4))
+        if op == 0:
+            R = int(rng.choice([1, 2, 4, 5, 8, 9, 10, 12]))
+            ss, sc = float(rng.uniform(0.8, 6.0)), float(rng.uniform(0.05, 1.0))
+            lay = ["texture", "linear"][int(rng.integers(0, 2))]
+            ref = (oracle.bilateral_texture if lay == "texture" else oracle.bilateral_linear)(f32, R, ss, sc)
+            err, tol = rel_err(ctx.bilateral(img, R, ss, sc, lay), ref), BIL_TOL
+        elif op == 1:
+            R = int(rng.choice([2, 4, 8]))
+            layers = [synth_ldr(rng, h, w) for _ in range(int(rng.integers(1, 4)))]
+            Wo = Z(h, w)
+            for l in layers:
+                Wo = oracle.bilateral_layers_accum(f32, l, Wo, R, 2.0, 0.2)
+            err, tol = rel_err(ctx.bilateral_layers(img, layers, R), oracle.normalize(Wo)), BIL_TOL
+        else:
+            cfg = [NLM_CFGS["ref"], NLM_CFGS["bench"], dict(search=(-4, 5), patch=(-2, 3)), dict(search=(-3, 2), patch=(-1, 2)),
+                   dict(search=(-5, 6), patch=(-3, 3))][int(rng.integers(0, 5))]
+            hp = float(rng.uniform(0.2, 1.5))
+            other = synth_ldr(rng, h, w) if ldr else (img * rng.gamma(16.0, 1 / 16.0, (h, w, 1))).astype(np.float32)
+            o32 = oracle.unpack_u8(other, 0) if ldr else other
+            if op == 2:
+                W0 = rng.random((h, w, 8), dtype=np.float32)
+                err = rel_err(ctx.nlm_accum(img, other, W0, hp, **cfg)[..., :5], oracle.nlm_accum(f32, o32, W0, hp, **cfg)[..., :5])
+            else:
+                got = ctx.nlm_temporal([img, other], k=1, hparam=hp, **cfg)
+                ref = oracle.nlm_temporal([f32, o32], k=1, hparam=hp, **cfg)
+                err = max(rel_err(a, b) for a, b in zip(got, ref))
+            tol = NLM_TOL
+        assert err < tol, (case, op, h, w, ldr, err)

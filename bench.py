@@ -311,7 +311,33 @@ def main():
     }
 
     # ---- outside the timed region -------------------------------------------------------------
+    # Nothing below may cost the headline: every extra is individually guarded, and a watchdog prints the
+    # line without the unfinished extras and ends every rank if they take longer than 5 minutes (a hung
+    # collective would otherwise lose the whole run).
+    import threading
     also = {}
+    printed = threading.Lock()
+
+    def emit():
+        if printed.acquire(blocking=False) and rank == 0:
+            res["also"] = also
+            res.setdefault("cpu_baseline", None)
+            print(json.dumps(res), flush=True)
+
+    def on_timeout():
+        also["error"] = "extras did not finish within 300 s; line emitted by the watchdog"
+        emit()
+        os._exit(0)
+    watchdog = threading.Timer(300.0, on_timeout)
+    watchdog.daemon = True
+    watchdog.start()
+
+    def guarded(name, fn):
+        try:
+            fn()
+        except Exception as e:          # an extra must never take the measurement down with it
+            also[name + "_error"] = f"{type(e).__name__}: {e}"
+
     if not args.no_extras:
         def time_gpu(fn, n=10):
             fn()
@@ -324,81 +350,103 @@ def main():
             torch.cuda.synchronize()
             return tm.ms()[0] / n / 1e3
 
-        for name, layout in (("bilateral_r8_linear", mid.LAYOUT_LINEAR), ("bilateral_r8_texture", mid.LAYOUT_TEXTURE)):
-            s = time_gpu(lambda: ctx.bilateral_dev(fptr[0], optr[0], W, H, 8, 2.0, 0.2, layout, mid.FMT_RGBA32F, stream))
-            also[name] = {"Mpixel/s": round(NPIX / 1e6 / s, 1), "ms": round(s * 1e3, 4),
-                          "valu_frac": round(BIL_FLOP_PER_PX * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
-                          "hbm_GBs": round(BIL_BYTES_PER_PX * NPIX / s / 1e9, 1),
-                          "hbm_frac": round(BIL_BYTES_PER_PX * NPIX / s / 1e9 / PEAK_HBM_GBS, 5)}
-        # BASELINE configs[3]: 4 RGBA8 guide layers, fused layer-aware bilateral r=8 (16+4L+16 B/px)
-        lay = [(f[..., :4].clamp(0, 1) * 255).to(torch.uint8).contiguous() for f in frames[:4]]
-        tbl = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in lay])
-        bp = mid.BilateralParams(W, H, 2.0, 0.2, 8, mid.LAYOUT_TEXTURE, mid.FMT_RGBA32F)
-        s = time_gpu(lambda: mid.lib.mid_bilateral_layers(ctx.handle, ctypes.byref(bp), fptr[0], tbl, 4, optr[0], stream))
-        also["bilateral_layers_r8_L4_fused"] = {"Mpixel/s": round(NPIX / 1e6 / s, 1), "ms": round(s * 1e3, 4),
-                                                "valu_frac": round(4 * BIL_FLOP_PER_PX * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
-                                                "hbm_GBs": round(48 * NPIX / s / 1e9, 1)}
-        # streaming passes (HBM bound): normalize 48 B/px, pack 20 B/px, unpack 20 B/px
-        # (buffers rotate over > 256 MiB so the Infinity Cache cannot serve the re-reads)
-        wbufs = [torch.rand((H, W, 8), device=device, dtype=torch.float32) + 0.5 for _ in range(6)]
-        rot = {"i": 0}
+        def extra_bilateral():
+            for name, layout in (("bilateral_r8_linear", mid.LAYOUT_LINEAR), ("bilateral_r8_texture", mid.LAYOUT_TEXTURE)):
+                s = time_gpu(lambda: ctx.bilateral_dev(fptr[0], optr[0], W, H, 8, 2.0, 0.2, layout, mid.FMT_RGBA32F, stream))
+                also[name] = {"Mpixel/s": round(NPIX / 1e6 / s, 1), "ms": round(s * 1e3, 4),
+                              "valu_frac": round(BIL_FLOP_PER_PX * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
+                              "hbm_GBs": round(BIL_BYTES_PER_PX * NPIX / s / 1e9, 1),
+                              "hbm_frac": round(BIL_BYTES_PER_PX * NPIX / s / 1e9 / PEAK_HBM_GBS, 5)}
 
-        def nxt(n):
-            rot["i"] += 1
-            return rot["i"] % n
-        np_ = mid.NormalizeParams(W, H)
-        s = time_gpu(lambda: mid.lib.mid_normalize(ctx.handle, ctypes.byref(np_), wbufs[nxt(6)].data_ptr(), optr[nxt(F)], stream), 24)
-        also["normalize"] = {"ms": round(s * 1e3, 4), "hbm_GBs": round(48 * NPIX / s / 1e9, 1), "hbm_frac": round(48 * NPIX / s / 1e9 / PEAK_HBM_GBS, 4)}
-        u8bufs = [torch.empty((H, W, 4), device=device, dtype=torch.uint8) for _ in range(8)]
-        s = time_gpu(lambda: mid.lib.mid_pack_u8(ctx.handle, wbufs[nxt(6)].data_ptr(), NPIX * 4, u8bufs[nxt(8)].data_ptr(), stream), 24)
-        also["pack_u8"] = {"ms": round(s * 1e3, 4), "hbm_GBs": round(20 * NPIX / s / 1e9, 1), "hbm_frac": round(20 * NPIX / s / 1e9 / PEAK_HBM_GBS, 4)}
-        s = time_gpu(lambda: mid.lib.mid_unpack_u8(ctx.handle, u8bufs[nxt(8)].data_ptr(), NPIX * 4, 0, wbufs[nxt(6)].data_ptr(), stream), 24)
-        also["unpack_u8"] = {"ms": round(s * 1e3, 4), "hbm_GBs": round(20 * NPIX / s / 1e9, 1), "hbm_frac": round(20 * NPIX / s / 1e9 / PEAK_HBM_GBS, 4)}
-        s1 = time_gpu(lambda: ctx.nlm_temporal_dev(fptr[:1], optr[:1], W, H, HPARAM, SEARCH, PATCH, 0, 0, 1, 0, stream))
-        also["nlm_single_frame_latency"] = {"ms": round(s1 * 1e3, 4), "Mpixel/s": round(NPIX / 1e6 / s1, 1)}
+        guarded("bilateral", extra_bilateral)
 
-        # temporal +-2 NLM over this rank's block, halo frames from the neighbours over RCCL
-        k = 2
-        n_seq = world * F
-        start, count = sharding.partition(n_seq, world)[rank]
+        def extra_layers():
+            # BASELINE configs[3]: 4 RGBA8 guide layers, fused layer-aware bilateral r=8 (16+4L+16 B/px)
+            lay = [(f[..., :4].clamp(0, 1) * 255).to(torch.uint8).contiguous() for f in frames[:4]]
+            tbl = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in lay])
+            bp = mid.BilateralParams(W, H, 2.0, 0.2, 8, mid.LAYOUT_TEXTURE, mid.FMT_RGBA32F)
+            s = time_gpu(lambda: mid.lib.mid_bilateral_layers(ctx.handle, ctypes.byref(bp), fptr[0], tbl, 4, optr[0], stream))
+            also["bilateral_layers_r8_L4_fused"] = {"Mpixel/s": round(NPIX / 1e6 / s, 1), "ms": round(s * 1e3, 4),
+                                                    "valu_frac": round(4 * BIL_FLOP_PER_PX * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                                    "hbm_GBs": round(48 * NPIX / s / 1e9, 1)}
 
-        def launch(fr, first, cnt, off):
-            ctx.nlm_temporal_dev([f.data_ptr() for f in fr], optr[off:off + cnt], W, H, HPARAM, SEARCH, PATCH,
-                                 k, first, cnt, mid.FMT_RGBA32F, stream)
+        guarded("layers", extra_layers)
 
-        def temporal_step():
-            # halo isend/irecv posted first, interior frames filtered meanwhile, boundary frames after the wait
-            sharding.temporal_block_overlapped(launch, frames, n_seq, k)
+        def extra_streaming():
+            # streaming passes (HBM bound): normalize 48 B/px, pack 20 B/px, unpack 20 B/px
+            # (buffers rotate over > 256 MiB so the Infinity Cache cannot serve the re-reads)
+            wbufs = [torch.rand((H, W, 8), device=device, dtype=torch.float32) + 0.5 for _ in range(6)]
+            rot = {"i": 0}
 
-        temporal_step()
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
+            def nxt(n):
+                rot["i"] += 1
+                return rot["i"] % n
+            np_ = mid.NormalizeParams(W, H)
+            s = time_gpu(lambda: mid.lib.mid_normalize(ctx.handle, ctypes.byref(np_), wbufs[nxt(6)].data_ptr(), optr[nxt(F)], stream), 24)
+            also["normalize"] = {"ms": round(s * 1e3, 4), "hbm_GBs": round(48 * NPIX / s / 1e9, 1), "hbm_frac": round(48 * NPIX / s / 1e9 / PEAK_HBM_GBS, 4)}
+            u8bufs = [torch.empty((H, W, 4), device=device, dtype=torch.uint8) for _ in range(8)]
+            s = time_gpu(lambda: mid.lib.mid_pack_u8(ctx.handle, wbufs[nxt(6)].data_ptr(), NPIX * 4, u8bufs[nxt(8)].data_ptr(), stream), 24)
+            also["pack_u8"] = {"ms": round(s * 1e3, 4), "hbm_GBs": round(20 * NPIX / s / 1e9, 1), "hbm_frac": round(20 * NPIX / s / 1e9 / PEAK_HBM_GBS, 4)}
+            s = time_gpu(lambda: mid.lib.mid_unpack_u8(ctx.handle, u8bufs[nxt(8)].data_ptr(), NPIX * 4, 0, wbufs[nxt(6)].data_ptr(), stream), 24)
+            also["unpack_u8"] = {"ms": round(s * 1e3, 4), "hbm_GBs": round(20 * NPIX / s / 1e9, 1), "hbm_frac": round(20 * NPIX / s / 1e9 / PEAK_HBM_GBS, 4)}
+
+        guarded("streaming", extra_streaming)
+
+        def extra_single_frame():
+            s1 = time_gpu(lambda: ctx.nlm_temporal_dev(fptr[:1], optr[:1], W, H, HPARAM, SEARCH, PATCH, 0, 0, 1, 0, stream))
+            also["nlm_single_frame_latency"] = {"ms": round(s1 * 1e3, 4), "Mpixel/s": round(NPIX / 1e6 / s1, 1)}
+
+        guarded("single_frame", extra_single_frame)
+
+        def extra_temporal():
+            # temporal +-2 NLM over this rank's block, halo frames from the neighbours over RCCL
+            k = 2
+            n_seq = world * F
+            start, count = sharding.partition(n_seq, world)[rank]
+
+            def launch(fr, first, cnt, off):
+                ctx.nlm_temporal_dev([f.data_ptr() for f in fr], optr[off:off + cnt], W, H, HPARAM, SEARCH, PATCH,
+                                     k, first, cnt, mid.FMT_RGBA32F, stream)
+
+            def temporal_step():
+                # halo isend/irecv posted first, interior frames filtered meanwhile, boundary frames after the wait
+                sharding.temporal_block_overlapped(launch, frames, n_seq, k)
+
             temporal_step()
-        torch.cuda.synchronize()
-        barrier()
-        te = (time.perf_counter() - t1) / reps
-        if world > 1:
-            t = torch.tensor([te], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            te = float(t.item())
-        also["temporal_nlm_k2"] = {"Mpixel/s_out": round(n_seq * NPIX / 1e6 / te, 1), "frames": n_seq,
-                                   "ms_per_sequence": round(te * 1e3, 3),
-                                   "halo": "RCCL isend/irecv of 2 frames per side, overlapped with the interior frames" if world > 1 else "none (1 rank)"}
+            torch.cuda.synchronize()
+            barrier()
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                temporal_step()
+            torch.cuda.synchronize()
+            barrier()
+            te = (time.perf_counter() - t1) / reps
+            if world > 1:
+                t = torch.tensor([te], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                te = float(t.item())
+            also["temporal_nlm_k2"] = {"Mpixel/s_out": round(n_seq * NPIX / 1e6 / te, 1), "frames": n_seq,
+                                       "ms_per_sequence": round(te * 1e3, 3),
+                                       "halo": "RCCL isend/irecv of 2 frames per side, overlapped with the interior frames" if world > 1 else "none (1 rank)"}
 
-        if rank == 0 and world == 1:
-            # PCIe-inclusive: pinned host frames in, host frames out, 3 streams (never `value`)
-            hf = [f.cpu().numpy() for f in frames]
-            ctx.sequence_nlm(hf[:2], k=0, overlap=True, search=SEARCH, patch=PATCH)      # first-touch of pinned memory
-            _, (wall, kern, copy) = ctx.sequence_nlm(hf, k=0, overlap=True, search=SEARCH, patch=PATCH)
-            _, (wall0, _, _) = ctx.sequence_nlm(hf, k=0, overlap=False, search=SEARCH, patch=PATCH)
-            also["pipeline_pcie_inclusive"] = {"Mpixel/s_overlap": round(len(hf) * NPIX / 1e3 / wall, 1),
-                                               "Mpixel/s_serial": round(len(hf) * NPIX / 1e3 / wall0, 1),
-                                               "frames": len(hf), "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3),
-                                               "note": "host RGBA32F frames in pinned memory -> H2D, NLM, D2H on 3 streams; "
-                                                       "serial = a sync after every step like the reference's fence"}
+        guarded("temporal", extra_temporal)
+
+        def extra_pipeline():
+            if rank == 0 and world == 1:
+                # PCIe-inclusive: pinned host frames in, host frames out, 3 streams (never `value`)
+                hf = [f.cpu().numpy() for f in frames]
+                ctx.sequence_nlm(hf[:2], k=0, overlap=True, search=SEARCH, patch=PATCH)      # first-touch of pinned memory
+                _, (wall, kern, copy) = ctx.sequence_nlm(hf, k=0, overlap=True, search=SEARCH, patch=PATCH)
+                _, (wall0, _, _) = ctx.sequence_nlm(hf, k=0, overlap=False, search=SEARCH, patch=PATCH)
+                also["pipeline_pcie_inclusive"] = {"Mpixel/s_overlap": round(len(hf) * NPIX / 1e3 / wall, 1),
+                                                   "Mpixel/s_serial": round(len(hf) * NPIX / 1e3 / wall0, 1),
+                                                   "frames": len(hf), "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3),
+                                                   "note": "host RGBA32F frames in pinned memory -> H2D, NLM, D2H on 3 streams; "
+                                                           "serial = a sync after every step like the reference's fence"}
+
+        guarded("pipeline", extra_pipeline)
+
     res["also"] = also
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -409,8 +457,8 @@ def main():
     elif rank == 0:
         res["cpu_baseline"] = None
 
-    if rank == 0:
-        print(json.dumps(res))
+    watchdog.cancel()
+    emit()
     if world > 1:
         dist.destroy_process_group()
 

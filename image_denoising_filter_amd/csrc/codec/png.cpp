@@ -190,8 +190,10 @@ bool png_encode(const uint8_t *rgba, int w, int h, std::vector<uint8_t> &file, s
 {
     if (w <= 0 || h <= 0 || !rgba) { err = "png: bad image"; return false; }
     const size_t rowbytes = (size_t)w * 4, bpp = 4;
-    std::vector<uint8_t> raw((rowbytes + 1) * h), cand(rowbytes);
-    for (int y = 0; y < h; ++y) {
+    std::vector<uint8_t> raw((rowbytes + 1) * h);
+    parallel_for((size_t)h, [&](size_t yy) {            // the filter choice of a row depends on the row above only
+        const int y = (int)yy;
+        std::vector<uint8_t> cand(rowbytes);
         const uint8_t *cur = rgba + (size_t)y * rowbytes, *prev = y ? cur - rowbytes : nullptr;
         uint8_t *dst = raw.data() + (size_t)y * (rowbytes + 1);
         long best = -1;
@@ -206,10 +208,33 @@ bool png_encode(const uint8_t *rgba, int w, int h, std::vector<uint8_t> &file, s
             }
             if (best < 0 || sum < best) { best = sum; dst[0] = (uint8_t)ft; memcpy(dst + 1, cand.data(), rowbytes); }
         }
-    }
-    uLongf clen = compressBound((uLong)raw.size());
-    std::vector<uint8_t> z(clen);
-    if (compress2(z.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { err = "png: zlib compress failed"; return false; }
+    });
+    // One zlib stream built from independently deflated segments (pigz style): every segment but the last
+    // ends on a full flush, so the raw-deflate pieces concatenate into a valid stream; header and Adler-32
+    // of the whole payload are added around them.  Any inflater (lodepng, libpng, Pillow) reads it.
+    const size_t seg_bytes = std::max<size_t>((size_t)1 << 20, (rowbytes + 1) * 16);
+    const size_t nseg = (raw.size() + seg_bytes - 1) / seg_bytes;
+    std::vector<std::vector<uint8_t>> parts(nseg);
+    std::vector<int> bad(nseg, 0);
+    parallel_for(nseg, [&](size_t si) {
+        const size_t off = si * seg_bytes, len = std::min(seg_bytes, raw.size() - off);
+        z_stream zs{};
+        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad[si] = 1; return; }
+        parts[si].resize(deflateBound(&zs, (uLong)len) + 16);
+        zs.next_in = (Bytef *)(raw.data() + off); zs.avail_in = (uInt)len;
+        zs.next_out = parts[si].data(); zs.avail_out = (uInt)parts[si].size();
+        const int rc = deflate(&zs, si + 1 == nseg ? Z_FINISH : Z_FULL_FLUSH);
+        if ((si + 1 == nseg && rc != Z_STREAM_END) || (si + 1 != nseg && (rc != Z_OK || zs.avail_in != 0))) bad[si] = 1;
+        parts[si].resize(zs.total_out);
+        deflateEnd(&zs);
+    });
+    for (int b : bad) if (b) { err = "png: zlib compress failed"; return false; }
+    std::vector<uint8_t> z;
+    z.push_back(0x78); z.push_back(0x9c);
+    for (auto &pz : parts) z.insert(z.end(), pz.begin(), pz.end());
+    const uLong ad = adler32(adler32(0L, Z_NULL, 0), raw.data(), (uInt)raw.size());
+    z.push_back(ad >> 24); z.push_back(ad >> 16); z.push_back(ad >> 8); z.push_back(ad);
+    const size_t clen = z.size();
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     file.assign(sig, sig + 8);
     uint8_t ihdr[13];

@@ -304,7 +304,8 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
     auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
-    if (int rc = ensure_lds(ctx, (const void *)kern, lds_bytes)) return rc;
+    // run-time-range instantiations are launched with different tile sizes: raise their limit to the device maximum once
+    if (int rc = ensure_lds(ctx, (const void *)kern, RTS ? (size_t)ctx->lds_max : lds_bytes)) return rc;
     a.tiles_x = (int)cdiv(a.w, VW);
     a.tiles_y = (int)cdiv(a.h, TILE_H);
     const unsigned nwg = (unsigned)a.tiles_x * a.tiles_y * (FUSED ? a.count : 1);

@@ -361,3 +361,15 @@ def test_random_parameter_sweep_against_oracle(ctx):
                 err = max(rel_err(a, b) for a, b in zip(got, ref))
             tol = NLM_TOL
         assert err < tol, (case, op, h, w, ldr, err)
+
+
+def test_runtime_range_kernel_small_then_large_window(ctx):
+    """The same run-time-range kernel first with a small LDS tile, then with a large one (its dynamic-LDS
+    limit must not stay at the first call's size)."""
+    rng = np.random.default_rng(90)
+    t = rng.random((40, 70, 4), dtype=np.float32)
+    nb = np.clip(t + 0.05 * rng.standard_normal((40, 70, 4)), 0, 1).astype(np.float32)
+    for search in ((-2, 3), (-14, 15), (-3, 4), (-20, 21)):
+        got = ctx.nlm_accum(t, nb, Z(40, 70), 0.5, search=search, patch=(-2, 3))
+        ref = oracle.nlm_accum(t, nb, Z(40, 70), 0.5, search=search, patch=(-2, 3))
+        assert rel_err(got[..., :5], ref[..., :5]) < 5e-5, search

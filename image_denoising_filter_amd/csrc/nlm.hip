@@ -183,10 +183,9 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
             // ds_read_b96 (8 LDS cycles) instead of ds_read_b128 (4).  One empty asm at the END of the
             // offset (tied to the last accumulator so it cannot be hoisted) keeps them formally live
             // without putting a wait in front of the distance phase.
-            if constexpr (PW - 1 == 6)
-                asm volatile("" ::"v"(n[0].w), "v"(n[1].w), "v"(n[2].w), "v"(n[NL + R].w), "v"(n[NL + R + 1].w), "v"(n[NL + R + 2].w), "v"(accw[R - 1]));
-            else if constexpr (PW - 1 == 5)
-                asm volatile("" ::"v"(n[0].w), "v"(n[1].w), "v"(n[2].w), "v"(n[NL + R].w), "v"(n[NL + R + 1].w), "v"(accw[R - 1]));
+#pragma unroll
+            for (int m = 0; m < DR; ++m)
+                if (m < NL || m >= NL + R) asm volatile("" ::"v"(n[m].w), "v"(accw[R - 1]));
         };
         auto load = [&](float4 (&n)[DR], const float4 *p) {
 #pragma unroll

@@ -114,6 +114,9 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
                     acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
                     accw[k] += wt;
                 }
+                // the guide's alpha is never used: keep it formally live so its read stays a
+                // ds_read_b128 (4 LDS cycles) instead of being narrowed to ds_read_b96 (8)
+                if (MODE != 0) asm volatile("" ::"v"(g.w), "v"(accw[P - 1]));
             }
         }
 #pragma unroll

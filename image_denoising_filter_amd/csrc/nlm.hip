@@ -8,7 +8,7 @@
 //   * a wave owns 64 adjacent columns x R rows; lane l owns one column, keeps its target
 //     column strip T(q) in VGPRs for the whole kernel and reads Nb(q+s) from an LDS tile
 //     (float4 per texel: one conflict-free ds_read_b128 per texel);
-//   * the vertical PW-tap sums are formed in registers with shared pair/quad partial sums;
+//   * the vertical PW-tap sums are formed in registers by block prefix/suffix sums (18 adds per 8 outputs);
 //   * the horizontal PW-tap sums move across lanes with whole-wave DPP shifts fused into
 //     v_add_f32 (no LDS traffic, no shuffles): 64-(PW-1) lanes hold finished patch distances;
 //   * v_exp_f32 with the -log2(e)/h^2 factor folded in, then 4 FMAs + 1 add per (pixel,offset).
@@ -36,27 +36,31 @@ struct NlmArgs {
     OutTable outs;
 };
 
+// V[k] = D[k] + ... + D[k+PW-1] for k = 0..R-1, with the block decomposition of van Herk / Gil-Werman:
+// cut D into blocks of PW values, form running sums from each block's end (S) and from each block's start
+// (Pf); a window that starts inside block b is S[k] (rest of block b) + Pf[k+PW-1] (head of block b+1), a
+// window that starts on a block boundary is that block's total.  PW=7, R=8: 18 additions for 8 outputs
+// instead of 36 with shared pair/quad sums (48 direct).  Every partial sum only ever adds non-negative
+// terms, so there is no cancellation; unused S/Pf entries are dead code after unrolling.
 template <int PW, int R>
 __device__ __forceinline__ void vertical_box(const float (&D)[R + PW - 1], float (&V)[R])
 {
-    if constexpr (PW == 7 || PW == 6) {
-        float P[R + 4];
+    constexpr int N = R + PW - 1;
+    float S[N], Pf[N];
 #pragma unroll
-        for (int m = 0; m < R + 4; ++m) P[m] = D[m] + D[m + 1];
+    for (int m = N - 1; m >= 0; --m) {
+        const bool block_end = (m % PW == PW - 1) || (m == N - 1);
+        S[m] = block_end ? D[m] : D[m] + S[m + 1];
+    }
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const float q = P[k] + P[k + 2];
-            if constexpr (PW == 7) V[k] = (q + P[k + 4]) + D[k + 6];
-            else                   V[k] = q + P[k + 4];
-        }
-    } else {
+    for (int m = 0; m < N; ++m) {
+        const bool block_start = (m % PW == 0);
+        Pf[m] = block_start ? D[m] : Pf[m - 1] + D[m];
+    }
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            float s = D[k];
-#pragma unroll
-            for (int j = 1; j < PW; ++j) s += D[k + j];
-            V[k] = s;
-        }
+    for (int k = 0; k < R; ++k) {
+        if (k % PW == 0) V[k] = (k == 0) ? S[0] : Pf[k + PW - 1];
+        else V[k] = S[k] + Pf[k + PW - 1];
     }
 }
 
@@ -319,20 +323,13 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
     // Tile shapes were chosen by A/B on MI355X (tools/ab_nlm.py): 4 waves x R rows per
     // workgroup (R=8: 76 KB of LDS), so two workgroups share a CU and one computes while the other
     // refills its tile; the search-column loop is unrolled 7x (21 = 3*7) / 2x (14 = 2*7).
-    // R=8 has the least redundant work per pixel; R=6 makes smaller workgroups.  All workgroups cost the
-    // same, so a launch takes ceil(workgroups / resident slots) rounds: pick the R whose
-    // rounds x (work per workgroup) is smallest -- for ONE 1080p frame R=8 needs 3 rounds of 512 slots for
-    // 2.26 rounds of work, R=6 fills 3 rounds almost exactly with 21 % less work in each.
+    // The tile shape is the same for every launch size on purpose: the block-sum decomposition of
+    // vertical_box makes the rounding of a pixel depend on its row within the strip, so a fixed R keeps
+    // the output bits independent of batch size, sharding and fused-vs-dispatch-sequence (tested).  (A
+    // shorter strip, R=6, filled the CUs better for ONE 1080p frame -- 0.69 vs 0.74 ms -- but would have
+    // made single-frame and batched results differ in the last bit.)
     const bool multi = FUSED && a.k > 0;
     static const int variant = getenv("MID_NLM_VARIANT") ? atoi(getenv("MID_NLM_VARIANT")) : 0;   // tuning A/B only
-    const int pw = p->patch_hi - p->patch_lo;
-    auto rounds_cost = [&](int R) {     // relative launch time of a 4-wave, 2-workgroups-per-CU tiling
-        const long wgs = (long)cdiv(a.w, 64 - (pw - 1)) * cdiv(a.h, 4 * R) * (FUSED ? a.count : 1);
-        const long slots = 2L * ctx->cu_count, rounds = (wgs + slots - 1) / slots;
-        const double per_out = 6.0 * (R + pw - 1) / R + (4.0 * R + 4) / R + 10.5 + 4.2 + 5.0;   // VALU units, DESIGN.md 3.1
-        return (double)rounds * R * per_out;
-    };
-    const bool small_r = !multi && variant == 0 && rounds_cost(6) < 0.97 * rounds_cost(8);
     if (p->search_lo == -10 && p->search_hi == 11 && p->patch_lo == -3 && p->patch_hi == 4) {   // 21x21 / 7x7 (benchmark)
         if (multi) {
             if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, FUSED, 1>(ctx, a, s);
@@ -341,12 +338,10 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
         if (variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, false, 3>(ctx, a, s);
         if (variant == 2) return launch_strip<-10, 11, -3, 4, 7, 12, FMT, FUSED, false, 3>(ctx, a, s);
         if (variant == 5) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s);
-        if (variant == 8 || small_r) return launch_strip<-10, 11, -3, 4, 6, 4, FMT, FUSED, false, 7>(ctx, a, s);
         return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7>(ctx, a, s);
     }
     if (p->search_lo == -7 && p->search_hi == 7 && p->patch_lo == -3 && p->patch_hi == 3) {     // nonlocal.comp:5-6 as shipped
         if (multi) return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, FUSED, 2>(ctx, a, s);
-        if (small_r) return launch_strip<-7, 7, -3, 3, 6, 4, FMT, FUSED, false, 2>(ctx, a, s);
         return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2>(ctx, a, s);
     }
     // Any other search window with one of the common patches: the same strip kernel with the search

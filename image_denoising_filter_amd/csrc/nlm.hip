@@ -17,13 +17,15 @@
 //
 // Out-of-image texels are vec4(0) for both images (LDS halo zero-filled).
 #include "common.hpp"
+#include <cmath>
 #include <cstdlib>
 
 namespace mid {
 
 struct NlmArgs {
     int w, h;
-    float kexp;            // -log2(e) / h^2
+    float kexp;            // -log2(e) / h^2 (per-pixel fallback kernel)
+    float sk, inv_sk;      // sqrt(log2(e))/h and its reciprocal: the strip kernels carry the exponent scale in the colours
     int tiles_x, tiles_y;
     // accumulate mode (one dispatch of nonlocal.comp)
     const void *target;
@@ -143,8 +145,10 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
     float Tr[DR], Tg[DR], Tb[DR];
 #pragma unroll
     for (int m = 0; m < DR; ++m) {
+        // Colours are pre-multiplied by sqrt(log2(e))/h, so the patch distance IS the exp2 argument and the
+        // multiply per (pixel, offset) disappears; the accumulated colours are unscaled once per frame.
         const float4 t = fetch_texture<FMT>(target, w, h, gx, yb + PLO + m);
-        Tr[m] = t.x; Tg[m] = t.y; Tb[m] = t.z;
+        Tr[m] = t.x * a.sk; Tg[m] = t.y * a.sk; Tb[m] = t.z * a.sk;
     }
 
     float4 tot[R];
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
     for (int f = f_lo; f <= f_hi; ++f) {
         const void *nb = FUSED ? a.frames.p[f] : a.neighbour;
         __syncthreads();   // previous frame's readers are done with the tile
-        fill_tile<FMT, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo, tid, NW * 64);
+        fill_tile<FMT, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo, tid, NW * 64, a.sk);
         __syncthreads();
         if (!wave_active) continue;
 
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const float d = horizontal_box<PLO, PHI>(V[k]);
-                const float wt = __builtin_amdgcn_exp2f(d * a.kexp);   // exp(-d/h^2), nonlocal.comp:55
+                const float wt = __builtin_amdgcn_exp2f(-d);           // exp(-d/h^2), nonlocal.comp:55 (d carries log2(e)/h^2)
                 const float4 c = n[k + NL];                             // centre texel Nb(p+s) of output row k
                 acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);   // :56
                 acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) {   // nlmData[p] += ..., nonlocal.comp:61-62
+            acc[k].x *= a.inv_sk; acc[k].y *= a.inv_sk; acc[k].z *= a.inv_sk;     // back to unscaled colours (alpha never was scaled)
             if (MULTI) {
                 tot[k].x += acc[k].x; tot[k].y += acc[k].y; tot[k].z += acc[k].z; tot[k].w += acc[k].w;
                 totw[k] += accw[k];
@@ -383,6 +388,13 @@ static float kexp_of(float hparam)
     return (float)(-1.4426950408889634 / ((double)hparam * (double)hparam));
 }
 
+static void set_scales(NlmArgs &a, float hparam)
+{
+    a.kexp = kexp_of(hparam);
+    a.sk = (float)(sqrt(1.4426950408889634) / (double)hparam);
+    a.inv_sk = (float)(1.0 / (double)a.sk);
+}
+
 }  // namespace mid
 
 using namespace mid;
@@ -395,7 +407,7 @@ extern "C" int mid_nlm_accum(mid_ctx *ctx, const mid_nlm_params *p, const void *
     if (int rc = check_params(p)) return rc;
     MID_REQUIRE(target && neighbour && W, "nlm_accum: NULL image pointer");
     NlmArgs a{};
-    a.w = p->width; a.h = p->height; a.kexp = kexp_of(p->filteringParameter);
+    a.w = p->width; a.h = p->height; set_scales(a, p->filteringParameter);
     a.target = target; a.neighbour = neighbour; a.W = W;
     a.n_frames = 1; a.k = 0; a.first = 0; a.count = 1;
     if (p->format == MID_FMT_RGBA8) return dispatch_ranges<MID_FMT_RGBA8, false>(ctx, p, a, b.s);
@@ -420,7 +432,7 @@ extern "C" int mid_nlm_temporal(mid_ctx *ctx, const mid_nlm_params *p, const voi
         const int lo = c0 - k < 0 ? 0 : c0 - k;
         const int hi = c0 + cn - 1 + k > n_frames - 1 ? n_frames - 1 : c0 + cn - 1 + k;
         NlmArgs a{};
-        a.w = p->width; a.h = p->height; a.kexp = kexp_of(p->filteringParameter);
+        a.w = p->width; a.h = p->height; set_scales(a, p->filteringParameter);
         a.n_frames = hi - lo + 1; a.k = k; a.first = c0 - lo; a.count = cn;
         for (int f = lo; f <= hi; ++f) {
             MID_REQUIRE(frames[f] != nullptr, "nlm_temporal: frame %d is NULL", f);

@@ -90,7 +90,9 @@ def test_constant_frame_properties(ctx):
     out = ctx.bilateral(img, 8, 2.0, 0.2)
     assert rel_err(out[8:-8, 8:-8], img[8:-8, 8:-8]) < 1e-6
     o = ctx.nlm_temporal([img], k=0, search=(-10, 11), patch=(-3, 4))[0]
-    assert rel_err(o[13:-13, 13:-13] * (441.001 / 441.0), img[13:-13, 13:-13]) < 2e-6
+    # (the strip kernel carries sqrt(log2 e)/h in the colours, so 441 equal addends are no longer powers of two:
+    #  ordinary fp32 summation error, inside the NLM tolerance)
+    assert rel_err(o[13:-13, 13:-13] * (441.001 / 441.0), img[13:-13, 13:-13]) < 2e-5
     assert np.all(o[0, 0, :3] < img[0, 0, :3])          # zero texels beyond the border take weight
 
 

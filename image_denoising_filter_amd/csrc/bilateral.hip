@@ -14,6 +14,7 @@
 // (2-D zero border vs flat index with row wrap-around), exactly the difference between
 // bialteral.comp:58-59 and bialteral_linear.comp:58.
 #include "common.hpp"
+#include <cmath>
 #include <cstdlib>
 
 namespace mid {
@@ -21,6 +22,7 @@ namespace mid {
 struct BilArgs {
     int w, h;
     float ks, kc;          // exponent scales (log2 domain)
+    float sc, inv_sc;      // sqrt(-kc) and its reciprocal: the tiled kernels carry the range scale in the guide colours
     int tiles_x, tiles_y;
     const void *in;
     float4 *out;           // plain / fused-layers output
@@ -57,7 +59,9 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
     const int gx = X0 + lane, yb = Y0 + wv * P;
     const bool wave_active = yb < h;
 
-    fill_tile<FMT, LINEAR>(img_t, LW, LH, a.in, w, h, X0 - R, Y0 - R, tid, NW * 64);
+    // The guide colours (the image itself in MODE 0) are pre-multiplied by sqrt(-kc), so -|dc|^2 is already the
+    // colour part of the exp2 argument and the FMA chain can start from the spatial term: 12 ops per tap, not 13.
+    fill_tile<FMT, LINEAR>(img_t, LW, LH, a.in, w, h, X0 - R, Y0 - R, tid, NW * 64, MODE == 0 ? a.sc : 1.0f);
 
     // spatial exponent by |j|: ks * j^2 (wave-uniform)
     float sj[R + 1];
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
     for (int pass = 0; pass < n_pass; ++pass) {
         if (MODE != 0) {
             __syncthreads();
-            fill_tile<MID_FMT_RGBA8, false>(gde_t, LW, LH, a.layers[pass], w, h, X0 - R, Y0 - R, tid, NW * 64);
+            fill_tile<MID_FMT_RGBA8, false>(gde_t, LW, LH, a.layers[pass], w, h, X0 - R, Y0 - R, tid, NW * 64, a.sc);
         }
         __syncthreads();
         if (!wave_active) continue;
@@ -108,8 +112,8 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
                     const int j = m - R - k;               // row offset of this texel for output k
                     if (j < -R || j > R) continue;
                     const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
-                    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    const float wt = __builtin_amdgcn_exp2f(fmaf(d2, a.kc, sij[j < 0 ? -j : j]));
+                    const float arg = fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, sij[j < 0 ? -j : j])));
+                    const float wt = __builtin_amdgcn_exp2f(arg);
                     acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
                     acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
                     accw[k] += wt;
@@ -121,6 +125,7 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
         }
 #pragma unroll
         for (int k = 0; k < P; ++k) {
+            if (MODE == 0) { acc[k].x *= a.inv_sc; acc[k].y *= a.inv_sc; acc[k].z *= a.inv_sc; }   // back to unscaled colours
             tot[k].x += acc[k].x; tot[k].y += acc[k].y; tot[k].z += acc[k].z; tot[k].w += acc[k].w;
             totw[k] += accw[k];
         }
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(512) void bilateral_rt_kernel(const BilArgs a, cons
     const int gx = X0 + lane, yb = Y0 + wv * P;
     const bool wave_active = yb < h;
 
-    fill_tile<FMT, LINEAR>(img_t, LW, LH, a.in, w, h, X0 - R, Y0 - R, tid, NW * 64);
+    fill_tile<FMT, LINEAR>(img_t, LW, LH, a.in, w, h, X0 - R, Y0 - R, tid, NW * 64, MODE == 0 ? a.sc : 1.0f);
     float4 tot[P];
     float totw[P];
 #pragma unroll
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(512) void bilateral_rt_kernel(const BilArgs a, cons
     for (int pass = 0; pass < n_pass; ++pass) {
         if (MODE != 0) {
             __syncthreads();
-            fill_tile<MID_FMT_RGBA8, false>(gde_t, LW, LH, a.layers[pass], w, h, X0 - R, Y0 - R, tid, NW * 64);
+            fill_tile<MID_FMT_RGBA8, false>(gde_t, LW, LH, a.layers[pass], w, h, X0 - R, Y0 - R, tid, NW * 64, a.sc);
         }
         __syncthreads();
         if (!wave_active) continue;
@@ -202,8 +207,7 @@ __global__ __launch_bounds__(512) void bilateral_rt_kernel(const BilArgs a, cons
                     const int j = m - R - k;
                     if (j < -R || j > R) continue;               // wave-uniform
                     const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
-                    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    const float wt = __builtin_amdgcn_exp2f(fmaf(d2, a.kc, fmaf(a.ks, (float)(j * j), si)));
+                    const float wt = __builtin_amdgcn_exp2f(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, fmaf(a.ks, (float)(j * j), si)))));
                     acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
                     acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
                     accw[k] += wt;
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(512) void bilateral_rt_kernel(const BilArgs a, cons
         }
 #pragma unroll
         for (int k = 0; k < P; ++k) {
+            if (MODE == 0) { acc[k].x *= a.inv_sc; acc[k].y *= a.inv_sc; acc[k].z *= a.inv_sc; }
             tot[k].x += acc[k].x; tot[k].y += acc[k].y; tot[k].z += acc[k].z; tot[k].w += acc[k].w;
             totw[k] += accw[k];
         }
@@ -351,6 +356,8 @@ static void fill_scales(const mid_bilateral_params *p, BilArgs &a)
     a.w = p->width; a.h = p->height;
     a.ks = (float)(-0.5 * 1.4426950408889634 / ((double)p->spatialSigma * (double)p->spatialSigma));
     a.kc = (float)(-0.5 * 1.4426950408889634 / ((double)p->colorSigma * (double)p->colorSigma));
+    a.sc = (float)(sqrt(0.5 * 1.4426950408889634) / (double)p->colorSigma);
+    a.inv_sc = (float)(1.0 / (double)a.sc);
 }
 
 }  // namespace mid

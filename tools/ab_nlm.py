@@ -20,6 +20,10 @@ for rep in range(3):
     tm.tock(0, s); torch.cuda.synchronize(); mt = tm.ms()[0] / 3
     print("variant", sys.argv[1], "batch8 %.3f ms %.0f Mpx/s | single %.3f ms %.0f Mpx/s | temporal k=2 8 frames %.3f ms %.0f out-Mpx/s %.0f pair-Mpx/s" % (m8, 8*bench.NPIX/m8/1e3, m1, bench.NPIX/m1/1e3, mt, 8*bench.NPIX/mt/1e3, 34*bench.NPIX/mt/1e3))
 '''
+code += r"""
+run(1, 2); o = outs[1].double()
+print("variant", sys.argv[1], "check sum %.9g  px %s  edge %s" % (o.sum().item(), [round(v, 7) for v in o[500, 700].tolist()], [round(v, 7) for v in o[1079, 1919].tolist()]))
+"""
 for v in sys.argv[1:]:
     env = dict(os.environ, MID_NLM_VARIANT=v)
     subprocess.run([sys.executable, "-c", code, v], env=env, check=True)

@@ -22,6 +22,11 @@ $(LIB): $(OBJS)
 # per-file extras: the NLM kernels gain 2-6 % from LLVM's max-ILP scheduling strategy (A/B on MI355X: 3074 vs 3011
 # Mpixel/s batched, 2882 vs 2710 single frame); the bilateral kernels lose 8 % with it, so it stays off there.
 EXTRA_nlm.hip := -mllvm -amdgpu-sched-strategy=max-ilp
+# `make TUNING=1` (after `make clean`) also builds the alternative NLM tile shapes that tools/ab_nlm.py selects
+# with MID_NLM_VARIANT; the shipped library has none of them.
+ifdef TUNING
+EXTRA_nlm.hip += -DMID_NLM_TUNING
+endif
 
 build/%.o: $(CSRC)/% $(CSRC)/common.hpp $(CSRC)/codec/image_io.hpp include/mi_denoise.h
 	@mkdir -p $(dir $@)

@@ -1,4 +1,5 @@
-"""A/B of NLM tile variants in separate processes (MID_NLM_VARIANT is read once per process)."""
+"""A/B of NLM tile variants in separate processes (MID_NLM_VARIANT is read once per process).
+Needs a library built with `make clean && make TUNING=1`; the shipped build only has variant 0."""
 import os, subprocess, sys
 code = r'''
 import sys, ctypes; sys.path.insert(0, ".")

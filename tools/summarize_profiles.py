@@ -47,6 +47,16 @@ if stats:
         for k, v in sorted(by.items()):
             w.writerow(list(k) + [len(v), round(sum(v) / len(v)), min(v), max(v)])
 
+main = sorted(glob.glob(os.path.join(src, "trace_main", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)
+if main:   # bench.py --no-extras: only the timed loop's launches, so Calls/AverageNs are those of the bench line
+    rows = list(csv.DictReader(open(main[0])))
+    with open(os.path.join(dst, f"{tag}_kernel_stats_timed_loop.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in [r for r in rows if "mid::" in r["Name"]] + [r for r in rows if "mid::" not in r["Name"]][:5]:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"], r["StdDev"]])
+
 # ---- PMC -------------------------------------------------------------------------------------
 pmc = defaultdict(lambda: defaultdict(list))
 newest = {}

@@ -76,13 +76,18 @@ def bilateral_layers_accum(img, layer_u8, W, radius, sigma_s=2.0, sigma_c=0.2):
     return W
 
 
-def nlm_accum(target, neighbour, W, hparam=0.5, search=(-7, 7), patch=(-3, 3)):
+def nlm_accum(target, neighbour, W, hparam=0.5, search=(-7, 7), patch=(-3, 3), threads=1):
+    """threads > 1: the same invocations spread over OpenMP threads (identical results; bench.py cpu_baseline)."""
     target, pt = _f32(target)
     neighbour, pn = _f32(neighbour)
     h, w = _hw(target)
     W = np.array(W, dtype=np.float32, order="C", copy=True)
-    _lib.orc_nlm_accum(pt, pn, w, h, _cf(hparam), search[0], search[1], patch[0], patch[1],
-                       W.ctypes.data_as(ctypes.c_void_p))
+    if threads > 1:
+        _lib.orc_nlm_accum_mt(pt, pn, w, h, _cf(hparam), search[0], search[1], patch[0], patch[1],
+                              W.ctypes.data_as(ctypes.c_void_p), int(threads))
+    else:
+        _lib.orc_nlm_accum(pt, pn, w, h, _cf(hparam), search[0], search[1], patch[0], patch[1],
+                           W.ctypes.data_as(ctypes.c_void_p))
     return W
 
 

@@ -135,35 +135,52 @@ void orc_bilateral_layers_accum(const float *img, const uint8_t *layer, int w, i
         }
 }
 
-/* a4 -- shaders/nonlocal.comp:28-72. */
+/* a4 -- shaders/nonlocal.comp:28-72.  One invocation (one pixel) of the shader. */
+static void nlm_invocation(const float *target, const float *neighbour, int w, int h, float h2,
+                           int search_lo, int search_hi, int patch_lo, int patch_hi, int px, int py, orc_weightinfo *W)
+{
+    float normWeight = 0.001f;                                           /* :32 */
+    vec4 wc = {0.f, 0.f, 0.f, 0.f};
+    for (int y = py + search_lo; y < py + search_hi; ++y)                /* :36 */
+        for (int x = px + search_lo; x < px + search_hi; ++x) {          /* :38 */
+            float colorDistance = 0.0f;
+            for (int j = patch_lo; j < patch_hi; ++j)                    /* :42 */
+                for (int i = patch_lo; i < patch_hi; ++i) {              /* :44 */
+                    vec4 t = fetch2d(target, w, h, px + i, py + j);      /* :46 */
+                    vec4 n = fetch2d(neighbour, w, h, x + i, y + j);     /* :47 */
+                    float dx = t.x - n.x, dy = t.y - n.y, dz = t.z - n.z;
+                    colorDistance += dx * dx + dy * dy + dz * dz;        /* :49-51 */
+                }
+            float weight = expf(-colorDistance / h2);                    /* :55 */
+            vec4 c = fetch2d(neighbour, w, h, x, y);                     /* :56 */
+            wc.x += c.x * weight; wc.y += c.y * weight;
+            wc.z += c.z * weight; wc.w += c.w * weight;
+            normWeight += weight;                                        /* :57 */
+        }
+    orc_weightinfo *o = W + ((long)py * w + px);
+    o->wc[0] += wc.x; o->wc[1] += wc.y; o->wc[2] += wc.z; o->wc[3] += wc.w;  /* :61 */
+    o->nw += normWeight;                                                 /* :62 */
+}
+
 void orc_nlm_accum(const float *target, const float *neighbour, int w, int h, float hparam,
                    int search_lo, int search_hi, int patch_lo, int patch_hi, orc_weightinfo *W)
 {
     const float h2 = hparam * hparam;                                            /* pow(h,2.f) :55 */
     for (int py = 0; py < h; ++py)
-        for (int px = 0; px < w; ++px) {
-            float normWeight = 0.001f;                                           /* :32 */
-            vec4 wc = {0.f, 0.f, 0.f, 0.f};
-            for (int y = py + search_lo; y < py + search_hi; ++y)                /* :36 */
-                for (int x = px + search_lo; x < px + search_hi; ++x) {          /* :38 */
-                    float colorDistance = 0.0f;
-                    for (int j = patch_lo; j < patch_hi; ++j)                    /* :42 */
-                        for (int i = patch_lo; i < patch_hi; ++i) {              /* :44 */
-                            vec4 t = fetch2d(target, w, h, px + i, py + j);      /* :46 */
-                            vec4 n = fetch2d(neighbour, w, h, x + i, y + j);     /* :47 */
-                            float dx = t.x - n.x, dy = t.y - n.y, dz = t.z - n.z;
-                            colorDistance += dx * dx + dy * dy + dz * dz;        /* :49-51 */
-                        }
-                    float weight = expf(-colorDistance / h2);                    /* :55 */
-                    vec4 c = fetch2d(neighbour, w, h, x, y);                     /* :56 */
-                    wc.x += c.x * weight; wc.y += c.y * weight;
-                    wc.z += c.z * weight; wc.w += c.w * weight;
-                    normWeight += weight;                                        /* :57 */
-                }
-            orc_weightinfo *o = W + ((long)py * w + px);
-            o->wc[0] += wc.x; o->wc[1] += wc.y; o->wc[2] += wc.z; o->wc[3] += wc.w;  /* :61 */
-            o->nw += normWeight;                                                 /* :62 */
-        }
+        for (int px = 0; px < w; ++px)
+            nlm_invocation(target, neighbour, w, h, h2, search_lo, search_hi, patch_lo, patch_hi, px, py, W);
+}
+
+/* The same invocations spread over OpenMP threads (rows are independent: identical results); used by
+ * bench.py's cpu_baseline so that the CPU figure is for the SAME workload as the GPU metric. */
+void orc_nlm_accum_mt(const float *target, const float *neighbour, int w, int h, float hparam,
+                      int search_lo, int search_hi, int patch_lo, int patch_hi, orc_weightinfo *W, int num_threads)
+{
+    const float h2 = hparam * hparam;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
+    for (int py = 0; py < h; ++py)
+        for (int px = 0; px < w; ++px)
+            nlm_invocation(target, neighbour, w, h, h2, search_lo, search_hi, patch_lo, patch_hi, px, py, W);
 }
 
 /* a5 -- shaders/normalize.comp:29-44. */

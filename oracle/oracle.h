@@ -42,6 +42,9 @@ void orc_bilateral_layers_accum(const float *img, const uint8_t *layer_rgba8, in
  * search [-7,7), patch [-3,3); the 21x21/7x7 metric is search [-10,11), patch [-3,4). W += ... */
 void orc_nlm_accum(const float *target, const float *neighbour, int w, int h, float hparam,
                    int search_lo, int search_hi, int patch_lo, int patch_hi, orc_weightinfo *W);
+/* same arithmetic, rows spread over OpenMP threads (bench.py cpu_baseline only) */
+void orc_nlm_accum_mt(const float *target, const float *neighbour, int w, int h, float hparam,
+                      int search_lo, int search_hi, int patch_lo, int patch_hi, orc_weightinfo *W, int num_threads);
 /* a5: shaders/normalize.comp:29-44. */
 void orc_normalize(const orc_weightinfo *W, int w, int h, float *out);
 

@@ -157,3 +157,13 @@ def test_u8_paths_exhaustive():
     assert np.array_equal(oracle.pack_u8(just_below), u8[1:] - 1), "truncation, not rounding"
     edge = np.float32([0.0, 1.0, 0.999999, -0.0, -0.5, -2.0, 1.5, np.nan, 254.999 / 255, 1 / 255, 0.00392])
     assert list(oracle.pack_u8(edge)) == [0, 255, 254, 0, 0, 0, 255, 0, 254, 1, 0]
+
+
+def test_threaded_nlm_restatement_is_the_same_arithmetic():
+    """bench.py's cpu_baseline spreads the shader invocations over OpenMP threads: results must not move."""
+    rng = np.random.default_rng(31)
+    t, nb = synth_hdr(rng, 23, 41), synth_hdr(rng, 23, 41)
+    W = rng.random((23, 41, 8)).astype(np.float32)
+    one = oracle.nlm_accum(t, nb, W, 0.5, (-10, 11), (-3, 4))
+    for th in (2, 5):
+        assert np.array_equal(oracle.nlm_accum(t, nb, W, 0.5, (-10, 11), (-3, 4), threads=th), one)

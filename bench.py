@@ -147,7 +147,7 @@ def cpu_baseline(workload="nlm"):
     done, spent, rows = 0, 0.0, 128
     img = (rng.random((rows, W, 4), dtype=np.float32) * 4).astype(np.float32)
     Wz = np.zeros((rows, W, 8), np.float32)
-    while spent < 12.0 and done < 8:                # 1920x128 strips (search halo clipped at the strip edge), ~12 s in all
+    while spent < 12.0 and done < 64:               # 1920x128 strips (search halo clipped at the strip edge), ~12 s in all
         t0 = time.perf_counter()
         acc = oracle.nlm_accum(img, img, Wz, HPARAM, SEARCH, PATCH, threads=threads)
         oracle.normalize(acc)

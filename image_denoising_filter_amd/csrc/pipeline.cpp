@@ -11,9 +11,10 @@
 //
 // joined only by events: compute(t) waits for upload(t+k); upload(f) waits for the last
 // compute that still reads the slot it overwrites; download(t) waits for compute(t);
-// compute(t) waits for download(t-2) before reusing an output slot.  Outputs go in batches of
-// B frames per launch; the ring holds 2k+2B frames, so the next batch streams in over PCIe
-// while this one is being filtered.  Host frames
+// compute(t) waits for download(t-3) before reusing an output slot.  Outputs go in batches of
+// B frames per launch; the ring holds 2k+3B frames and there are three output slots, so uploads
+// run up to two batches ahead of the kernel and downloads up to two behind: the three stages
+// are decoupled and the slowest one (not their jitter) sets the frame rate.  Host frames
 // allocated with mid_alloc_host (pinned) are DMA'd directly; pageable memory still works but
 // HIP stages it and the overlap is lost.
 //
@@ -82,11 +83,12 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
     if (B > count) B = count;
     if (2 * k + 2 * B > kMaxFrames) B = (kMaxFrames - 2 * k) / 2;
     const int nb = (count + B - 1) / B;
-    const int ring = n_up < 2 * k + 2 * B ? n_up : 2 * k + 2 * B;
+    constexpr int DEPTH = 3;                                  // batches in flight per stage
+    const int ring = n_up < 2 * k + DEPTH * B ? n_up : 2 * k + DEPTH * B;
 
     DeviceBufs dring, dout;
     if (int rc = dring.make(ring, in_bytes)) return rc;
-    if (int rc = dout.make(2 * B, out_bytes)) return rc;
+    if (int rc = dout.make(DEPTH * B, out_bytes)) return rc;
     EventPool up0, up1, c0, c1, d0, d1;
     for (EventPool *e : {&up0, &up1}) if (int rc = e->make(n_up)) return rc;
     for (EventPool *e : {&c0, &c1, &d0, &d1}) if (int rc = e->make(nb)) return rc;
@@ -109,18 +111,18 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
     for (int bi = 0; bi < nb; ++bi) {
         const int b0 = first + bi * B, bn = (first + count - b0) < B ? (first + count - b0) : B;
         const int need = b0 + bn - 1 + k < n - 1 ? b0 + bn - 1 + k : n - 1;
-        const int ahead = overlap ? (need + B < f_hi ? need + B : f_hi) : need;
-        // frames up to the batch's last window must be resident; with overlap the next batch's frames are
-        // started now as well: they only wait for the previous batch's kernel and ride beside this one
+        const int ahead = overlap ? (need + (DEPTH - 1) * B < f_hi ? need + (DEPTH - 1) * B : f_hi) : need;
+        // frames up to the batch's last window must be resident; with overlap the next two batches' frames are
+        // started now as well: they only wait for kernels already enqueued and ride beside this one
         while (next_upload <= need) { if (int rc = upload(next_upload++)) return rc; }
         MID_HIP(hipStreamWaitEvent(ctx->compute, up1.ev[need - f_lo], 0));
-        if (bi >= 2) MID_HIP(hipStreamWaitEvent(ctx->compute, d1.ev[bi - 2], 0));
+        if (bi >= DEPTH) MID_HIP(hipStreamWaitEvent(ctx->compute, d1.ev[bi - DEPTH], 0));
 
         const int lo = b0 - k < 0 ? 0 : b0 - k;
         const void *tbl[kMaxFrames];
         for (int f = lo; f <= need; ++f) tbl[f - lo] = slot(f);
         mid_pixel *o[kMaxFrames];
-        for (int i = 0; i < bn; ++i) o[i] = (mid_pixel *)dout.p[(bi & 1) * B + i];
+        for (int i = 0; i < bn; ++i) o[i] = (mid_pixel *)dout.p[(bi % DEPTH) * B + i];
         MID_HIP(hipEventRecord(c0.ev[bi], ctx->compute));
         if (int rc = mid_nlm_temporal(ctx, p, tbl, need - lo + 1, k, b0 - lo, bn, o, ctx->compute)) return rc;
         MID_HIP(hipEventRecord(c1.ev[bi], ctx->compute));
@@ -130,7 +132,7 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
         MID_HIP(hipStreamWaitEvent(ctx->download, c1.ev[bi], 0));
         MID_HIP(hipEventRecord(d0.ev[bi], ctx->download));
         for (int i = 0; i < bn; ++i)
-            MID_HIP(hipMemcpyAsync(host_out[b0 - first + i], dout.p[(bi & 1) * B + i], out_bytes, hipMemcpyDeviceToHost, ctx->download));
+            MID_HIP(hipMemcpyAsync(host_out[b0 - first + i], dout.p[(bi % DEPTH) * B + i], out_bytes, hipMemcpyDeviceToHost, ctx->download));
         MID_HIP(hipEventRecord(d1.ev[bi], ctx->download));
 
         if (!overlap) {   // the reference's behaviour: a fence wait after every submit (src/main.cpp:1092)
@@ -187,7 +189,8 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
 
     DeviceBufs dtarget, dslot, dW, dout;
     if (int rc = dtarget.make(1, in_bytes)) return rc;
-    if (int rc = dslot.make(n > 1 ? 2 : 1, in_bytes)) return rc;
+    constexpr int SLOTS = 3;                                   // neighbour frames in flight: uploads run two dispatches ahead
+    if (int rc = dslot.make(n < SLOTS ? n : SLOTS, in_bytes)) return rc;
     if (int rc = dW.make(1, npix * sizeof(mid_weightinfo))) return rc;
     if (int rc = dout.make(1, out_bytes)) return rc;
     EventPool up0, up1, c0, c1, misc;
@@ -204,22 +207,24 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
     MID_HIP(hipStreamWaitEvent(ctx->compute, misc.ev[1], 0));
 
     auto upload = [&](int f) -> int {
-        if (f >= 2) MID_HIP(hipStreamWaitEvent(ctx->upload, c1.ev[f - 2], 0));   // slot still read by dispatch f-2
+        if (f >= SLOTS) MID_HIP(hipStreamWaitEvent(ctx->upload, c1.ev[f - SLOTS], 0));   // slot still read by dispatch f-SLOTS
         MID_HIP(hipEventRecord(up0.ev[f], ctx->upload));
-        MID_HIP(hipMemcpyAsync(dslot.p[f & 1], host_frames[f], in_bytes, hipMemcpyHostToDevice, ctx->upload));
+        MID_HIP(hipMemcpyAsync(dslot.p[f % SLOTS], host_frames[f], in_bytes, hipMemcpyHostToDevice, ctx->upload));
         MID_HIP(hipEventRecord(up1.ev[f], ctx->upload));
         return MID_OK;
     };
-    if (int rc = upload(0)) return rc;
+    int next_upload = 0;
     for (int f = 0; f < n; ++f) {
-        if (overlap && f + 1 < n) { if (int rc = upload(f + 1)) return rc; }     // rides beside dispatch f
+        // overlap: frames f+1, f+2 ride beside dispatch f (their slots were last read by dispatches already enqueued)
+        const int ahead = overlap ? (f + SLOTS - 1 < n - 1 ? f + SLOTS - 1 : n - 1) : f;
+        while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }
         MID_HIP(hipStreamWaitEvent(ctx->compute, up1.ev[f], 0));
         MID_HIP(hipEventRecord(c0.ev[f], ctx->compute));
-        if (int rc = mid_nlm_accum(ctx, p, dtarget.p[0], dslot.p[f & 1], (mid_weightinfo *)dW.p[0], ctx->compute)) return rc;
+        if (int rc = mid_nlm_accum(ctx, p, dtarget.p[0], dslot.p[f % SLOTS], (mid_weightinfo *)dW.p[0], ctx->compute)) return rc;
         MID_HIP(hipEventRecord(c1.ev[f], ctx->compute));
         if (!overlap) {   // fence after every submit, src/main.cpp:1092
             MID_HIP(hipStreamSynchronize(ctx->compute));
-            if (f + 1 < n) { if (int rc = upload(f + 1)) return rc; MID_HIP(hipStreamSynchronize(ctx->upload)); }
+            MID_HIP(hipStreamSynchronize(ctx->upload));
         }
     }
     mid_normalize_params np{p->width, p->height};

@@ -463,7 +463,7 @@ def main():
 
         def extra_pipeline():
             if rank == 0 and world == 1:
-                # PCIe-inclusive: pinned host frames in, host frames out, 3 streams (never `value`)
+                # PCIe-inclusive: pinned host frames in, host frames out, overlapped streams (never `value`)
                 hf = [f.cpu().numpy() for f in frames]
                 ctx.sequence_nlm(hf[:2], k=0, overlap=True, search=SEARCH, patch=PATCH)      # first-touch of pinned memory
                 _, (wall, kern, copy) = ctx.sequence_nlm(hf, k=0, overlap=True, search=SEARCH, patch=PATCH)
@@ -471,7 +471,7 @@ def main():
                 also["pipeline_pcie_inclusive"] = {"Mpixel/s_overlap": round(len(hf) * NPIX / 1e3 / wall, 1),
                                                    "Mpixel/s_serial": round(len(hf) * NPIX / 1e3 / wall0, 1),
                                                    "frames": len(hf), "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3),
-                                                   "note": "host RGBA32F frames in pinned memory -> H2D, NLM, D2H on 3 streams; "
+                                                   "note": "host RGBA32F frames in pinned memory -> H2D, NLM (two alternating kernel streams), D2H, all overlapped; "
                                                            "serial = a sync after every step like the reference's fence"}
 
         guarded("pipeline", extra_pipeline)

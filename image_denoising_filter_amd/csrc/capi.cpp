@@ -1,7 +1,7 @@
 // capi.cpp -- context, error, memory and timer entry points of libmi_denoise.so.
 // Replaces the Vulkan bootstrap and buffer factories of the reference
 // (src/vk_utils.cpp:13-305, src/main.cpp:247-401) with plain HIP: a context is a device
-// plus three streams (compute / upload / download).
+// plus its streams (compute, a second compute stream for the frame pipeline, upload, download).
 #include "common.hpp"
 
 namespace mid {
@@ -54,6 +54,7 @@ extern "C" int mid_ctx_create(int device, mid_ctx **out)
     if (c->lds_max < 160 * 1024 && (int)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024) c->lds_max = 160 * 1024;
     snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
     if (hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->compute2, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->upload, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->download, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -68,9 +69,11 @@ extern "C" void mid_ctx_destroy(mid_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->compute);
+    (void)hipStreamSynchronize(ctx->compute2);
     (void)hipStreamSynchronize(ctx->upload);
     (void)hipStreamSynchronize(ctx->download);
     (void)hipStreamDestroy(ctx->compute);
+    (void)hipStreamDestroy(ctx->compute2);
     (void)hipStreamDestroy(ctx->upload);
     (void)hipStreamDestroy(ctx->download);
     delete ctx;

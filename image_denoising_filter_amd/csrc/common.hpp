@@ -11,6 +11,7 @@
 struct mid_ctx {
     int device;
     hipStream_t compute;   // default stream for kernels
+    hipStream_t compute2;  // second kernel stream of the frame pipeline (consecutive frames alternate)
     hipStream_t upload;    // H2D stream of the frame pipeline
     hipStream_t download;  // D2H stream of the frame pipeline
     int lds_max;           // max dynamic LDS per workgroup (bytes)

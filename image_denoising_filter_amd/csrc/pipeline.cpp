@@ -3,18 +3,19 @@
 // Replaces the reference's single-queue ping-pong (RecordCommandsOfOverlappingNLM,
 // src/main.cpp:889-989, loop :1539-1573: one command buffer holding "dispatch on texture A"
 // followed, without a barrier, by "copy staging -> texture B", descriptor sets swapped by
-// parity, and a fence wait after every submit).  Here three HIP streams run concurrently:
+// parity, and a fence wait after every submit).  Here the stages run concurrently on their own HIP streams:
 //
 //   upload   : hipMemcpyAsync host frame f -> device ring slot f % RING
-//   compute  : temporal NLM of output frame t over ring slots t-k..t+k
+//   compute  : temporal NLM of output frame t over ring slots t-k..t+k (two kernel streams, frames alternate)
 //   download : hipMemcpyAsync device out slot t % 2 -> host
 //
 // joined only by events: compute(t) waits for upload(t+k); upload(f) waits for the last
 // compute that still reads the slot it overwrites; download(t) waits for compute(t);
-// compute(t) waits for download(t-3) before reusing an output slot.  Outputs go in batches of
-// B frames per launch; the ring holds 2k+3B frames and there are three output slots, so uploads
-// run up to two batches ahead of the kernel and downloads up to two behind: the three stages
-// are decoupled and the slowest one (not their jitter) sets the frame rate.  Host frames
+// compute(t) waits for download(t-4) before reusing an output slot.  Outputs go in batches of
+// B frames per launch; the ring holds 2k+4B frames and there are four output slots, so uploads
+// run up to three batches ahead of the kernel and downloads up to three behind: the stages are
+// decoupled and the slowest one (measured: the 33 MB/frame download, 0.70 ms) sets the frame
+// rate.  Host frames
 // allocated with mid_alloc_host (pinned) are DMA'd directly; pageable memory still works but
 // HIP stages it and the overlap is lost.
 //
@@ -83,7 +84,7 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
     if (B > count) B = count;
     if (2 * k + 2 * B > kMaxFrames) B = (kMaxFrames - 2 * k) / 2;
     const int nb = (count + B - 1) / B;
-    constexpr int DEPTH = 3;                                  // batches in flight per stage
+    constexpr int DEPTH = 4;                                  // batches in flight per stage
     const int ring = n_up < 2 * k + DEPTH * B ? n_up : 2 * k + DEPTH * B;
 
     DeviceBufs dring, dout;
@@ -112,20 +113,24 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
         const int b0 = first + bi * B, bn = (first + count - b0) < B ? (first + count - b0) : B;
         const int need = b0 + bn - 1 + k < n - 1 ? b0 + bn - 1 + k : n - 1;
         const int ahead = overlap ? (need + (DEPTH - 1) * B < f_hi ? need + (DEPTH - 1) * B : f_hi) : need;
-        // frames up to the batch's last window must be resident; with overlap the next two batches' frames are
+        // frames up to the batch's last window must be resident; with overlap the next batches' frames are
         // started now as well: they only wait for kernels already enqueued and ride beside this one
         while (next_upload <= need) { if (int rc = upload(next_upload++)) return rc; }
-        MID_HIP(hipStreamWaitEvent(ctx->compute, up1.ev[need - f_lo], 0));
-        if (bi >= DEPTH) MID_HIP(hipStreamWaitEvent(ctx->compute, d1.ev[bi - DEPTH], 0));
+        // Consecutive batches go to alternating kernel streams: every dependency between them is an explicit
+        // event (inputs, ring-slot reuse, output-slot reuse), so the tail of one launch -- 1156 workgroups on 512
+        // slots leave the last round a quarter full -- overlaps the head of the next instead of idling the CUs.
+        hipStream_t cs = overlap && (bi & 1) ? ctx->compute2 : ctx->compute;
+        MID_HIP(hipStreamWaitEvent(cs, up1.ev[need - f_lo], 0));
+        if (bi >= DEPTH) MID_HIP(hipStreamWaitEvent(cs, d1.ev[bi - DEPTH], 0));
 
         const int lo = b0 - k < 0 ? 0 : b0 - k;
         const void *tbl[kMaxFrames];
         for (int f = lo; f <= need; ++f) tbl[f - lo] = slot(f);
         mid_pixel *o[kMaxFrames];
         for (int i = 0; i < bn; ++i) o[i] = (mid_pixel *)dout.p[(bi % DEPTH) * B + i];
-        MID_HIP(hipEventRecord(c0.ev[bi], ctx->compute));
-        if (int rc = mid_nlm_temporal(ctx, p, tbl, need - lo + 1, k, b0 - lo, bn, o, ctx->compute)) return rc;
-        MID_HIP(hipEventRecord(c1.ev[bi], ctx->compute));
+        MID_HIP(hipEventRecord(c0.ev[bi], cs));
+        if (int rc = mid_nlm_temporal(ctx, p, tbl, need - lo + 1, k, b0 - lo, bn, o, cs)) return rc;
+        MID_HIP(hipEventRecord(c1.ev[bi], cs));
 
         while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }
 
@@ -143,6 +148,7 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
     }
     MID_HIP(hipStreamSynchronize(ctx->upload));
     MID_HIP(hipStreamSynchronize(ctx->compute));
+    MID_HIP(hipStreamSynchronize(ctx->compute2));
     MID_HIP(hipStreamSynchronize(ctx->download));
     const auto wall1 = std::chrono::steady_clock::now();
 

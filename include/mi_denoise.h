@@ -163,8 +163,9 @@ int mid_pack_u8(mid_ctx *ctx, const float *in, size_t n_values, uint8_t *out, vo
  * Replaces RecordCommandsOfOverlappingNLM + the ping-pong loop (src/main.cpp:889-989,
  * :1539-1573): host frames in, host frames out.  Frame t+k+1 is uploaded (hipMemcpyAsync from
  * pinned slots on an upload stream) while frame t is filtered on the compute stream and frame
- * t-1 is downloaded on a third stream; a device ring keeps 2k+3 frames and three
- * output slots in flight, so each stage may run up to two frames away from its neighbours.
+ * t-1 is downloaded on a third stream; a device ring keeps 2k+4 frames and four
+ * output slots in flight, so each stage may run up to three frames away from its neighbours, and
+ * consecutive frames are filtered on two alternating kernel streams (one launch's tail overlaps the next one's head).
  * host_frames/host_out are arrays of n_frames HOST pointers (RGBA32F or RGBA8 per p->format;
  * output always RGBA32F).  Synchronous: returns when every output is on the host.
  * timings_ms (optional, 3 floats): total wall, sum of kernel time, sum of copy time. */

@@ -473,6 +473,13 @@ def main():
                                                    "frames": len(hf), "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3),
                                                    "note": "host RGBA32F frames in pinned memory -> H2D, NLM (two alternating kernel streams), D2H, all overlapped; "
                                                            "serial = a sync after every step like the reference's fence"}
+                # the reference's LDR path: RGBA8 frames in, RGBA8 frames out (u8 conversion on the device)
+                lf = [np.clip(f * 64.0, 0, 255).astype(np.uint8) for f in hf]
+                ctx.sequence_nlm(lf[:2], k=0, overlap=True, search=SEARCH, patch=PATCH, out_u8=True)
+                _, (wall8, kern8, copy8) = ctx.sequence_nlm(lf, k=0, overlap=True, search=SEARCH, patch=PATCH, out_u8=True)
+                also["pipeline_pcie_inclusive_ldr"] = {"Mpixel/s_overlap": round(len(lf) * NPIX / 1e3 / wall8, 1), "frames": len(lf),
+                                                       "kernel_ms": round(kern8, 3), "copy_ms": round(copy8, 3),
+                                                       "note": "host RGBA8 frames in, RGBA8 frames out (mid_sequence_nlm_range_u8)"}
 
         guarded("pipeline", extra_pipeline)
 

@@ -83,6 +83,9 @@ _SIGNATURES = {
     "mid_sequence_nlm_range": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), c_void_pp, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, c_void_pp, ctypes.c_int,
                                               ctypes.POINTER(ctypes.c_float)]),
+    "mid_sequence_nlm_range_u8": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), c_void_pp, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int, c_void_pp, ctypes.c_int,
+                                                 ctypes.POINTER(ctypes.c_float)]),
     "mid_nlm_multiframe": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), _P, c_void_pp, ctypes.c_int, _P, ctypes.c_int,
                                           ctypes.POINTER(ctypes.c_float)]),
     "mid_image_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Image)]),

@@ -258,15 +258,16 @@ class Context:
         return out, tuple(t)
 
     def sequence_nlm(self, frames, k=2, overlap=True, hparam=0.5, search=(-7, 7), patch=(-3, 3), pinned=True,
-                     first=0, count=None):
-        """Host frames in, host frames out through the 3-stream pipeline (mid_sequence_nlm[_range]).
+                     first=0, count=None, out_u8=False):
+        """Host frames in, host frames out through the overlapped pipeline (mid_sequence_nlm_range[_u8]).
+        out_u8: outputs converted to RGBA8 on the device like the reference's read-back (src/main.cpp:97-103).
         Returns (outputs for frames first..first+count-1, (wall_ms, kernel_ms, copy_ms))."""
         frames = [_img(f) for f in frames]
         n = len(frames)
         count = n - first if count is None else count
         h, w = frames[0].shape[:2]
         fmt = _fmt_of(frames[0])
-        in_bytes, out_bytes = frames[0].nbytes, w * h * 16
+        in_bytes, out_bytes = frames[0].nbytes, w * h * (4 if out_u8 else 16)
         hin, hout = [], []
         try:
             for f in frames:
@@ -283,11 +284,12 @@ class Context:
                 hout.append(q.value)
             prm = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], fmt)
             t = (ctypes.c_float * 3)()
-            _check(lib.mid_sequence_nlm_range(self.handle, ctypes.byref(prm), (ctypes.c_void_p * n)(*hin), n, k, first, count,
-                                              (ctypes.c_void_p * count)(*hout), 1 if overlap else 0, t), "mid_sequence_nlm_range")
+            entry = lib.mid_sequence_nlm_range_u8 if out_u8 else lib.mid_sequence_nlm_range
+            _check(entry(self.handle, ctypes.byref(prm), (ctypes.c_void_p * n)(*hin), n, k, first, count,
+                         (ctypes.c_void_p * count)(*hout), 1 if overlap else 0, t), "mid_sequence_nlm_range")
             outs = []
             for q in hout:
-                o = np.empty((h, w, 4), np.float32)
+                o = np.empty((h, w, 4), np.uint8 if out_u8 else np.float32)
                 ctypes.memmove(o.ctypes.data, q, out_bytes)
                 outs.append(o)
             return outs, tuple(t)

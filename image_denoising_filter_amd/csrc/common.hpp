@@ -49,6 +49,11 @@ struct Bind {
 
 inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
+// mid_nlm_temporal with the output format as an argument: out_u8 != 0 writes RGBA8 frames (pack_rgba8 of the
+// normalized pixel) instead of float4 ones -- used by the frame pipeline's u8 variant, not exported.
+int nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *const *frames, int n_frames, int k,
+                     int first, int count, void *const *out, int out_u8, void *stream);
+
 // Raise the dynamic-LDS limit of `kern` once per context (kernels here use up to 160 KB).
 inline int ensure_lds(mid_ctx *ctx, const void *kern, size_t bytes)
 {
@@ -65,11 +70,34 @@ constexpr int kMaxFrames = 96;
 struct FrameTable { const void *p[kMaxFrames]; };
 struct OutTable   { void *p[kMaxFrames]; };
 
-// UNORM texel decode, src/texture.cpp:16: c/255 (IEEE-correct division, no fast-math).
+// UNORM texel decode, src/texture.cpp:16: the correctly rounded quotient c/255 for c = 0..255.  A product with
+// 1/255 alone is off by one ulp for 126 of the 256 codes; one residual correction (r = c - 255 q exactly, q += r/255)
+// lands on the IEEE quotient for all 256 -- checked exhaustively in exact arithmetic and by the bit-exact u8 tests --
+// in 3 instructions instead of the ~12 plus two mode switches of a full fp32 division.
+__device__ __forceinline__ float unorm8(float c)
+{
+    const float k = 1.0f / 255.0f;
+    const float q = c * k;
+    return fmaf(fmaf(-q, 255.0f, c), k, q);
+}
 __device__ __forceinline__ float4 decode_rgba8(uint32_t v)
 {
-    return make_float4((float)(v & 0xffu) / 255.0f, (float)((v >> 8) & 0xffu) / 255.0f,
-                       (float)((v >> 16) & 0xffu) / 255.0f, (float)(v >> 24) / 255.0f);
+    return make_float4(unorm8((float)(v & 0xffu)), unorm8((float)((v >> 8) & 0xffu)),
+                       unorm8((float)((v >> 16) & 0xffu)), unorm8((float)(v >> 24)));
+}
+
+// u8 encode of the reference's read-back, src/main.cpp:97-103: (unsigned char)(255.0f * v), truncation, all four
+// channels; clamped only where that C cast is undefined (v <= -1, v >= 256, NaN).
+__device__ __forceinline__ uint32_t pack1(float x)
+{
+    const float v = 255.0f * x;                       // src/main.cpp:99
+    if (!(v > -1.0f)) return 0u;                      // C cast undefined (and NaN): clamp
+    if (v >= 256.0f) return 255u;
+    return (uint32_t)(int)v;                          // truncation toward zero
+}
+__device__ __forceinline__ uint32_t pack_rgba8(float4 p)
+{
+    return pack1(p.x) | (pack1(p.y) << 8) | (pack1(p.z) << 16) | (pack1(p.w) << 24);
 }
 
 // 2-D fetch with the zero-texel policy for out-of-image coordinates (texelFetch of the

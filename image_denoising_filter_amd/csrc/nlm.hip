@@ -34,6 +34,7 @@ struct NlmArgs {
     int slo, shi;          // run-time search range of the RTS instantiations
     // fused temporal mode
     int n_frames, k, first, count;
+    int out_u8;            // fused mode: outputs are RGBA8 frames (pack_rgba8) instead of float4
     FrameTable frames;
     OutTable outs;
 };
@@ -233,7 +234,8 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
             float4 o;
             if (totw[k] == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);       // normalize.comp:36-38
             else o = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
-            ((float4 *)a.outs.p[fz])[idx] = o;
+            if (a.out_u8) ((uint32_t *)a.outs.p[fz])[idx] = pack_rgba8(o);
+            else ((float4 *)a.outs.p[fz])[idx] = o;
         } else {
             float4 *wp = (float4 *)(a.W + idx);
             float4 wc = wp[0], nw = wp[1];
@@ -290,7 +292,8 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
         float4 o;
         if (totw == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);
         else o = make_float4(tot.x / totw, tot.y / totw, tot.z / totw, tot.w / totw);
-        ((float4 *)a.outs.p[fz])[idx] = o;
+        if (a.out_u8) ((uint32_t *)a.outs.p[fz])[idx] = pack_rgba8(o);
+        else ((float4 *)a.outs.p[fz])[idx] = o;
     } else {
         float4 *wp = (float4 *)(a.W + idx);
         float4 wc = wp[0], nw = wp[1];
@@ -421,6 +424,12 @@ extern "C" int mid_nlm_temporal(mid_ctx *ctx, const mid_nlm_params *p, const voi
                                 int n_frames, int k, int first, int count, mid_pixel *const *out,
                                 void *stream)
 {
+    return mid::nlm_temporal_out(ctx, p, frames, n_frames, k, first, count, (void *const *)out, 0, stream);
+}
+
+int mid::nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *const *frames, int n_frames, int k,
+                          int first, int count, void *const *out, int out_u8, void *stream)
+{
     Bind b(ctx, stream);
     if (b.rc) return b.rc;
     if (int rc = check_params(p)) return rc;
@@ -436,7 +445,7 @@ extern "C" int mid_nlm_temporal(mid_ctx *ctx, const mid_nlm_params *p, const voi
         const int hi = c0 + cn - 1 + k > n_frames - 1 ? n_frames - 1 : c0 + cn - 1 + k;
         NlmArgs a{};
         a.w = p->width; a.h = p->height; set_scales(a, p->filteringParameter);
-        a.n_frames = hi - lo + 1; a.k = k; a.first = c0 - lo; a.count = cn;
+        a.n_frames = hi - lo + 1; a.k = k; a.first = c0 - lo; a.count = cn; a.out_u8 = out_u8;
         for (int f = lo; f <= hi; ++f) {
             MID_REQUIRE(frames[f] != nullptr, "nlm_temporal: frame %d is NULL", f);
             a.frames.p[f - lo] = frames[f];

@@ -58,9 +58,9 @@ struct DeviceBufs {
 
 // Outputs [first, first+count) of an n-frame host sequence; frames outside that range are only
 // uploaded as far as the temporal window needs them (the halo of a frame block).
-extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
-                                      int n, int k, int first, int count, mid_pixel *const *host_out,
-                                      int overlap, float *timings_ms)
+static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
+                         int n, int k, int first, int count, void *const *host_out, bool out_u8,
+                         int overlap, float *timings_ms)
 {
     Bind b(ctx, nullptr);
     if (b.rc) return b.rc;
@@ -74,7 +74,8 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
     for (int i = 0; i < count; ++i) MID_REQUIRE(host_out[i], "sequence_nlm: output %d is NULL", i);
 
     const size_t npix = (size_t)p->width * p->height;
-    const size_t in_bytes = npix * (p->format == MID_FMT_RGBA8 ? 4 : 16), out_bytes = npix * 16;
+    const size_t in_bytes = npix * (p->format == MID_FMT_RGBA8 ? 4 : 16);
+    const size_t dl_bytes = npix * (out_u8 ? 4 : 16);            // one output frame, as it is written and downloaded
     const int n_up = f_hi - f_lo + 1;
     // Outputs can be filtered in batches of B frames per launch.  Measured on MI355X (16 x 1080p, 21x21/7x7):
     // B=1 2084 Mpixel/s, B=2 1341, B=4 1472, B=8 1403 -- coarser batches bunch the copies and lose overlap
@@ -89,7 +90,7 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
 
     DeviceBufs dring, dout;
     if (int rc = dring.make(ring, in_bytes)) return rc;
-    if (int rc = dout.make(DEPTH * B, out_bytes)) return rc;
+    if (int rc = dout.make(DEPTH * B, dl_bytes)) return rc;
     EventPool up0, up1, c0, c1, d0, d1;
     for (EventPool *e : {&up0, &up1}) if (int rc = e->make(n_up)) return rc;
     for (EventPool *e : {&c0, &c1, &d0, &d1}) if (int rc = e->make(nb)) return rc;
@@ -119,6 +120,7 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
         // Consecutive batches go to alternating kernel streams: every dependency between them is an explicit
         // event (inputs, ring-slot reuse, output-slot reuse), so the tail of one launch -- 1156 workgroups on 512
         // slots leave the last round a quarter full -- overlaps the head of the next instead of idling the CUs.
+        // (measured: one kernel stream 2385, two 2575, three 1892, four 1652 Mpixel/s)
         hipStream_t cs = overlap && (bi & 1) ? ctx->compute2 : ctx->compute;
         MID_HIP(hipStreamWaitEvent(cs, up1.ev[need - f_lo], 0));
         if (bi >= DEPTH) MID_HIP(hipStreamWaitEvent(cs, d1.ev[bi - DEPTH], 0));
@@ -129,7 +131,9 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
         mid_pixel *o[kMaxFrames];
         for (int i = 0; i < bn; ++i) o[i] = (mid_pixel *)dout.p[(bi % DEPTH) * B + i];
         MID_HIP(hipEventRecord(c0.ev[bi], cs));
-        if (int rc = mid_nlm_temporal(ctx, p, tbl, need - lo + 1, k, b0 - lo, bn, o, cs)) return rc;
+        // out_u8: GetImageFromGPU's u8 conversion (src/main.cpp:97-103) in the kernel's epilogue -- a quarter of the
+        // bytes to write and to download
+        if (int rc = nlm_temporal_out(ctx, p, tbl, need - lo + 1, k, b0 - lo, bn, (void *const *)o, out_u8 ? 1 : 0, cs)) return rc;
         MID_HIP(hipEventRecord(c1.ev[bi], cs));
 
         while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }
@@ -137,7 +141,7 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
         MID_HIP(hipStreamWaitEvent(ctx->download, c1.ev[bi], 0));
         MID_HIP(hipEventRecord(d0.ev[bi], ctx->download));
         for (int i = 0; i < bn; ++i)
-            MID_HIP(hipMemcpyAsync(host_out[b0 - first + i], dout.p[(bi % DEPTH) * B + i], out_bytes, hipMemcpyDeviceToHost, ctx->download));
+            MID_HIP(hipMemcpyAsync(host_out[b0 - first + i], dout.p[(bi % DEPTH) * B + i], dl_bytes, hipMemcpyDeviceToHost, ctx->download));
         MID_HIP(hipEventRecord(d1.ev[bi], ctx->download));
 
         if (!overlap) {   // the reference's behaviour: a fence wait after every submit (src/main.cpp:1092)
@@ -172,6 +176,20 @@ extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, con
         timings_ms[2] = copy;
     }
     return MID_OK;
+}
+
+extern "C" int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
+                                      int n, int k, int first, int count, mid_pixel *const *host_out,
+                                      int overlap, float *timings_ms)
+{
+    return sequence_impl(ctx, p, host_frames, n, k, first, count, (void *const *)host_out, false, overlap, timings_ms);
+}
+
+extern "C" int mid_sequence_nlm_range_u8(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
+                                         int n, int k, int first, int count, uint8_t *const *host_out,
+                                         int overlap, float *timings_ms)
+{
+    return sequence_impl(ctx, p, host_frames, n, k, first, count, (void *const *)host_out, true, overlap, timings_ms);
 }
 
 extern "C" int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint32_t *__restrict_
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
         const uint32_t v = in[i];
         const float r = (float)(v & 0xffu), g = (float)((v >> 8) & 0xffu), b = (float)((v >> 16) & 0xffu), a = (float)(v >> 24);
-        if (FLAVOUR == 0) out[i] = make_float4(r / 255.0f, g / 255.0f, b / 255.0f, a / 255.0f);
+        if (FLAVOUR == 0) out[i] = make_float4(unorm8(r), unorm8(g), unorm8(b), unorm8(a));
         else {
             const float k = 1.0f / 255.0f;                                       // src/main.cpp:1804
             out[i] = make_float4(r * k, g * k, b * k, a * k);
@@ -37,22 +37,14 @@ template <int FLAVOUR>
 __global__ __launch_bounds__(256) void unpack_tail_kernel(const uint8_t *in, float *out, size_t n0, size_t n)
 {
     const size_t i = n0 + threadIdx.x;
-    if (i < n) out[i] = FLAVOUR == 0 ? (float)in[i] / 255.0f : (float)in[i] * (1.0f / 255.0f);
-}
-
-__device__ __forceinline__ uint32_t pack1(float x)
-{
-    const float v = 255.0f * x;                       // src/main.cpp:99
-    if (!(v > -1.0f)) return 0u;                      // C cast undefined (and NaN): clamp
-    if (v >= 256.0f) return 255u;
-    return (uint32_t)(int)v;                          // truncation toward zero
+    if (i < n) out[i] = FLAVOUR == 0 ? unorm8((float)in[i]) : (float)in[i] * (1.0f / 255.0f);
 }
 
 __global__ __launch_bounds__(256) void pack_kernel(const float4 *__restrict__ in, uint32_t *__restrict__ out, size_t npix)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) {
         const float4 p = in[i];
-        out[i] = pack1(p.x) | (pack1(p.y) << 8) | (pack1(p.z) << 16) | (pack1(p.w) << 24);
+        out[i] = pack_rgba8(p);
     }
 }
 

@@ -176,6 +176,12 @@ int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const void *const *h
 int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
                            int n_frames, int k, int first, int count, mid_pixel *const *host_out,
                            int overlap, float *timings_ms);
+/* Same, with the reference's u8 read-back conversion (GetImageFromGPU, src/main.cpp:97-103: truncating
+ * (unsigned char)(255.0f*v), see mid_pack_u8) done on the device before the download: host_out receives RGBA8
+ * frames, a quarter of the PCIe bytes -- the LDR (PNG in, PNG out) path of the reference. */
+int mid_sequence_nlm_range_u8(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
+                              int n_frames, int k, int first, int count, uint8_t *const *host_out,
+                              int overlap, float *timings_ms);
 
 /* The reference's literal multi-frame mode (src/main.cpp:1539-1606): ONE target, its neighbour frames
  * streamed from the host.  W = sum over frames of one nonlocal.comp dispatch each (target fixed), then

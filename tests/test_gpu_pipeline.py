@@ -32,3 +32,20 @@ def test_sequence_ldr_frames(ctx):
     outs, _ = ctx.sequence_nlm(frames, k=1)
     ref = oracle.nlm_temporal([oracle.unpack_u8(f, 0) for f in frames], k=1)
     assert max(rel_err(a, b) for a, b in zip(outs, ref)) < 2e-5
+
+
+@pytest.mark.parametrize("k,n", [(1, 5), (0, 9)])
+def test_sequence_u8_output_is_the_references_readback_conversion(ctx, k, n):
+    """mid_sequence_nlm_range_u8 == float pipeline followed by (unsigned char)(255.0f*v) (src/main.cpp:97-103), bit for bit."""
+    from conftest import synth_ldr
+    rng = np.random.default_rng(40 + k)
+    frames = [synth_ldr(rng, 37, 66) for _ in range(n)]
+    f32, _ = ctx.sequence_nlm(frames, k=k)
+    for overlap in (True, False):
+        u8, _ = ctx.sequence_nlm(frames, k=k, overlap=overlap, out_u8=True)
+        assert len(u8) == n and u8[0].dtype == np.uint8
+        for a, b in zip(u8, f32):
+            assert np.array_equal(a, oracle.pack_u8(b))
+    # a sub-range, as a frame-block shard would ask for it
+    part, _ = ctx.sequence_nlm(frames, k=k, first=1, count=2, out_u8=True)
+    assert all(np.array_equal(a, oracle.pack_u8(b)) for a, b in zip(part, f32[1:3]))

@@ -167,3 +167,42 @@ def test_threaded_nlm_restatement_is_the_same_arithmetic():
     one = oracle.nlm_accum(t, nb, W, 0.5, (-10, 11), (-3, 4))
     for th in (2, 5):
         assert np.array_equal(oracle.nlm_accum(t, nb, W, 0.5, (-10, 11), (-3, 4), threads=th), one)
+
+
+def test_three_instruction_unorm8_decode_equals_the_ieee_quotient_for_all_codes():
+    """csrc/common.hpp unorm8(): q = c*(1/255); q += (c - 255 q)*(1/255) with two fmas.  In exact rational arithmetic
+    with round-to-nearest-even to 24 bits this is the correctly rounded c/255 (what UNORM decode and the oracle's
+    c/255.0f give) for every one of the 256 codes; the plain product alone is not (126 codes differ by one ulp)."""
+    from fractions import Fraction
+    import math
+
+    def rnd32(x):
+        if x == 0:
+            return Fraction(0)
+        s, x = (1 if x > 0 else -1), abs(x)
+        e = math.floor(math.log2(x))
+        while Fraction(2) ** e > x:
+            e -= 1
+        while Fraction(2) ** (e + 1) <= x:
+            e += 1
+        ulp = Fraction(2) ** (e - 23)
+        q = x / ulp
+        n = q.numerator // q.denominator
+        rem = q - n
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and n % 2 == 1):
+            n += 1
+        return s * n * ulp
+
+    k = rnd32(Fraction(1, 255))
+    assert float(k) == float(np.float32(1.0) / np.float32(255.0))
+    product_only_wrong = 0
+    for c in range(256):
+        want = rnd32(Fraction(c, 255))
+        assert float(want) == float(np.float32(c) / np.float32(255.0))
+        q0 = rnd32(Fraction(c) * k)
+        product_only_wrong += q0 != want
+        r = rnd32(Fraction(c) - 255 * q0)          # fma: exact product-sum, one rounding
+        assert rnd32(r * k + q0) == want, c
+    assert product_only_wrong == 126
+    assert np.array_equal(oracle.unpack_u8(np.arange(256, dtype=np.uint8), 0),
+                          (np.arange(256, dtype=np.float32) / np.float32(255.0)))

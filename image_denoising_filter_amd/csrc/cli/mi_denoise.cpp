@@ -291,7 +291,11 @@ public:
         }
         const int w = frames[0].w, h = frames[0].h, fmt = frames[0].format;
         std::vector<const void *> in(n);
-        std::vector<std::vector<Pixel>> out(n, std::vector<Pixel>((size_t)w * h));
+        // LDR frames come back as RGBA8: the read-back conversion of GetImageFromGPU (:97-103) runs on the device
+        // (mid_sequence_nlm_range_u8), a quarter of the download
+        const bool hdr = fmt == MID_FMT_RGBA32F;
+        std::vector<std::vector<Pixel>> out(hdr ? n : 0, std::vector<Pixel>((size_t)w * h));
+        std::vector<std::vector<unsigned char>> out8(hdr ? 0 : n, std::vector<unsigned char>((size_t)w * h * 4));
         for (int i = 0; i < n; ++i) in[i] = frames[i].bytes.data();
         const int G = std::max(1, std::min(opt.gpus, n));
         std::vector<std::string> errors(G);
@@ -307,10 +311,16 @@ public:
                     MID_CHECK(mid_ctx_create(opt.device + g, &ctx));
                     struct CtxGuard { mid_ctx *c; ~CtxGuard() { mid_ctx_destroy(c); } } guard{ctx};
                     mid_nlm_params p{w, h, opt.nlm_h, opt.search_lo, opt.search_hi, opt.patch_lo, opt.patch_hi, fmt};
-                    std::vector<mid_pixel *> o(count);
-                    for (int i = 0; i < count; ++i) o[i] = (mid_pixel *)out[start + i].data();
                     float t[3] = {0, 0, 0};
-                    MID_CHECK(mid_sequence_nlm_range(ctx, &p, in.data(), n, k, start, count, o.data(), 1, t));
+                    if (hdr) {
+                        std::vector<mid_pixel *> o(count);
+                        for (int i = 0; i < count; ++i) o[i] = (mid_pixel *)out[start + i].data();
+                        MID_CHECK(mid_sequence_nlm_range(ctx, &p, in.data(), n, k, start, count, o.data(), 1, t));
+                    } else {
+                        std::vector<uint8_t *> o(count);
+                        for (int i = 0; i < count; ++i) o[i] = out8[start + i].data();
+                        MID_CHECK(mid_sequence_nlm_range_u8(ctx, &p, in.data(), n, k, start, count, o.data(), 1, t));
+                    }
                     kern[g] = t[1]; copy[g] = t[2];
                 } catch (const std::exception &e) { errors[g] = e.what(); }
             });
@@ -321,8 +331,14 @@ public:
         m_transferMs = *std::max_element(copy.begin(), copy.end());
         std::cout << "\t" << n << " frames, k=" << k << ", " << G << " device(s): " << sec << " sec, "
                   << (double)n * w * h / 1e6 / sec << " Mpixel/s end to end\n";
-        const bool hdr = fmt == MID_FMT_RGBA32F;
-        for (int i = 0; i < n; ++i) save("output-animation-" + fs::path(frameNames[i]).stem().string(), out[i], w, h, hdr);
+        for (int i = 0; i < n; ++i) {
+            const std::string name = "output-animation-" + fs::path(frameNames[i]).stem().string();
+            if (hdr) save(name, out[i], w, h, true);
+            else {
+                std::cout << "\t\tencoding png\n";
+                MID_CHECK(mid_image_save(out_path(name + ".png").c_str(), out8[i].data(), w, h, MID_FMT_RGBA8));   // lodepng::encode :1717
+            }
+        }
     }
 
     void save(std::string name, const std::vector<Pixel> &px, int w, int h, bool hdr) const

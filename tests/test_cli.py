@@ -158,6 +158,24 @@ def test_animation_mode(tmp_path):
 
 
 @pytest.mark.gpu
+def test_animation_mode_ldr_frames_come_back_as_u8(tmp_path):
+    """PNG animation: the u8 read-back conversion runs on the device (mid_sequence_nlm_range_u8); the PNGs must hold
+    (unsigned char)(255*v) of the temporal filter, up to the one-LSB truncation boundary of a 1e-5 float difference."""
+    d, frames, _, ext = _make_animation(tmp_path, False, n=5)
+    out = tmp_path / "o"
+    out.mkdir()
+    r = _run([str(d / "Animation01_X_0000.png"), "--animation", "--temporal-k", "1", "--outdir", str(out)], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = oracle.nlm_temporal([oracle.unpack_u8(f, 0) for f in frames], k=1)
+    for i in range(5):
+        got = mid.load_image(out / f"output-animation-Animation01_X_{i:04d}.png")
+        want = oracle.pack_u8(ref[i])
+        assert got.dtype == np.uint8 and got.shape == want.shape
+        diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert diff.max() <= 1 and np.mean(diff[..., :3] == 0) >= 0.999, i
+
+
+@pytest.mark.gpu
 def test_sequence_range_blocks_equal_whole(ctx):
     """mid_sequence_nlm_range over blocks == the whole sequence (the unit of frame-block sharding)."""
     rng = np.random.default_rng(5)

@@ -1,11 +1,12 @@
 // exr.cpp -- minimal scanline OpenEXR codec over zlib (the reference calls tinyexr's LoadEXR /
 // SaveEXR, src/main.cpp:155,1699,1744,1887; tinyexr is an un-vendored submodule, absent here).
 //
-// Read: single-part scanline files, compression NONE / RLE / ZIPS / ZIP / PIZ (piz.cpp), channel types UINT / HALF /
-// FLOAT, any data window, increasing or decreasing line order.  Channels R,G,B,A are looked up by name
+// Read: single-part scanline files and single-level (ONE_LEVEL) tiled files, compression NONE / RLE / ZIPS / ZIP /
+// PIZ (piz.cpp) / PXR24, channel types UINT / HALF / FLOAT, any data window, increasing or decreasing line order
+// -- the set tinyexr's LoadEXR accepts.  Channels R,G,B,A are looked up by name
 // (a layer prefix "xxx.R" is accepted when no plain names exist); a missing A reads as 1.0 and a
 // single-channel file is replicated into RGB -- the behaviour of tinyexr's LoadEXR that the reference
-// relies on (README.md:59 "alpha is kept").  Tiled, multi-part, deep and PXR24/B44/DWA files are
+// relies on (README.md:59 "alpha is kept").  Mip/rip-mapped tiles, multi-part, deep and B44/DWA files are
 // rejected with a message naming the feature.
 // Write: channels A,B,G,R as FLOAT, ZIP blocks of 16 lines (NONE when the image is smaller than
 // 16x16), the attribute set tinyexr's SaveEXR(data, w, h, 4, 0, ...) emits.
@@ -109,13 +110,49 @@ static bool rle_decode(const uint8_t *in, size_t n, std::vector<uint8_t> &out, s
     return out.size() == expect;
 }
 
+// PXR24 (ImfPxr24Compressor): per scanline and channel the values are delta-coded and split into byte planes (most
+// significant first) -- 2 planes for HALF, 3 for FLOAT (the float's low 8 mantissa bits are dropped: lossy), 4 for
+// UINT -- and the whole block is deflated.  Output: the standard scanline layout.
+static bool pxr24_decode(const uint8_t *in, size_t n_in, long bw, long nl, const std::vector<int> &types,
+                         std::vector<uint8_t> &out, std::string &err)
+{
+    size_t planes_per_line = 0, line_bytes = 0;
+    for (int t : types) { planes_per_line += t == 1 ? 2 : t == 2 ? 3 : 4; line_bytes += (size_t)bw * (t == 1 ? 2 : 4); }
+    const size_t packed = planes_per_line * (size_t)bw * (size_t)nl;
+    std::vector<uint8_t> tmp(packed);
+    uLongf got = (uLongf)packed;
+    if (uncompress(tmp.data(), &got, in, (uLong)n_in) != Z_OK || got != packed) { err = "exr: corrupt PXR24 chunk"; return false; }
+    out.resize(line_bytes * (size_t)nl);
+    const uint8_t *p = tmp.data();
+    uint8_t *q = out.data();
+    for (long l = 0; l < nl; ++l)
+        for (int t : types) {
+            const int np = t == 1 ? 2 : t == 2 ? 3 : 4;
+            const uint8_t *pl[4] = {p, p + bw, p + 2 * bw, p + 3 * bw};
+            p += (size_t)np * bw;
+            uint32_t pixel = 0;
+            for (long x = 0; x < bw; ++x) {
+                if (t == 1) {
+                    pixel += ((uint32_t)pl[0][x] << 8) | pl[1][x];
+                    const uint16_t hv = (uint16_t)pixel;
+                    memcpy(q, &hv, 2); q += 2;
+                } else {
+                    if (t == 2) pixel += ((uint32_t)pl[0][x] << 24) | ((uint32_t)pl[1][x] << 16) | ((uint32_t)pl[2][x] << 8);
+                    else pixel += ((uint32_t)pl[0][x] << 24) | ((uint32_t)pl[1][x] << 16) | ((uint32_t)pl[2][x] << 8) | pl[3][x];
+                    memcpy(q, &pixel, 4); q += 4;
+                }
+            }
+        }
+    return true;
+}
+
 bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<float> &rgba, std::string &err)
 {
     Reader r{file.data(), file.data() + file.size()};
     if (file.size() < 8 || r.i32() != 20000630) { err = "exr: not an OpenEXR file"; return false; }
     const int32_t ver = r.i32();
     if ((ver & 0xff) != 2) { err = "exr: unsupported version"; return false; }
-    if (ver & 0x200) { err = "exr: tiled files are not supported"; return false; }
+    const bool tiled = (ver & 0x200) != 0;
     if (ver & 0x800) { err = "exr: deep data is not supported"; return false; }
     if (ver & 0x1000) { err = "exr: multi-part files are not supported"; return false; }
 
@@ -123,6 +160,8 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
     int compression = -1, line_order = 0;
     int32_t dw[4] = {0, 0, -1, -1};
     bool have_dw = false;
+    uint32_t tile_w = 0, tile_h = 0;
+    int tile_mode = -1;
     for (;;) {
         const std::string name = r.str();
         if (!r.ok) { err = "exr: truncated header"; return false; }
@@ -147,21 +186,28 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
         } else if (name == "compression") compression = a.u8();
         else if (name == "dataWindow") { for (int i = 0; i < 4; ++i) dw[i] = a.i32(); have_dw = a.ok; }
         else if (name == "lineOrder") line_order = a.u8();
+        else if (name == "tiles") { tile_w = (uint32_t)a.i32(); tile_h = (uint32_t)a.i32(); tile_mode = a.u8(); if (!a.ok) tile_mode = -1; }
     }
     (void)line_order;   // chunks carry their own y; the offset table is indexed by block either way
     if (chans.empty() || !have_dw || compression < 0) { err = "exr: missing channels/dataWindow/compression"; return false; }
     static const char *cname[] = {"NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
-    if (compression > 4) { err = std::string("exr: compression ") + (compression < 10 ? cname[compression] : "?") + " is not supported (NONE/RLE/ZIPS/ZIP/PIZ only)"; return false; }
+    if (compression > 5) { err = std::string("exr: compression ") + (compression < 10 ? cname[compression] : "?") + " is not supported (NONE/RLE/ZIPS/ZIP/PIZ/PXR24 only)"; return false; }
+    if (tiled) {
+        if (tile_mode < 0 || tile_w == 0 || tile_h == 0 || tile_w > 65536 || tile_h > 65536) { err = "exr: tiled file without a valid tiles attribute"; return false; }
+        if ((tile_mode & 0xf) != 0) { err = "exr: mip/rip-mapped tiles are not supported (ONE_LEVEL only)"; return false; }
+    }
     const long W = (long)dw[2] - dw[0] + 1, H = (long)dw[3] - dw[1] + 1;
     if (W <= 0 || H <= 0 || W > 65536 || H > 65536) { err = "exr: bad data window"; return false; }
     if ((double)W * H * 2 > (double)file.size() * 1100.0) { err = "exr: data window larger than the file can hold"; return false; }
-    size_t line_bytes = 0;
-    std::vector<size_t> choff(chans.size());
+    size_t px_bytes = 0;                       // bytes of one pixel over all channels; a line of a block bw wide holds bw * px_bytes
+    std::vector<size_t> chpre(chans.size());   // bytes per pixel of the channels stored before channel c
+    std::vector<int> types(chans.size());
     for (size_t c = 0; c < chans.size(); ++c) {
         if (chans[c].xs != 1 || chans[c].ys != 1) { err = "exr: subsampled channels are not supported"; return false; }
         if (chans[c].type < 0 || chans[c].type > 2) { err = "exr: unknown pixel type"; return false; }
-        choff[c] = line_bytes;
-        line_bytes += (size_t)W * (chans[c].type == 1 ? 2 : 4);
+        chpre[c] = px_bytes;
+        types[c] = chans[c].type;
+        px_bytes += chans[c].type == 1 ? 2 : 4;
     }
     // channel -> RGBA slot
     int slot[4] = {-1, -1, -1, -1};
@@ -180,10 +226,12 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
     int gray_ch = -1;
     if (gray) for (size_t c = 0; c < chans.size(); ++c) if ((int)c != slot[3]) gray_ch = (int)c;
 
-    const int lines_per_block = compression == 3 ? 16 : compression == 4 ? 32 : 1;
+    const int lines_per_block = compression == 3 || compression == 5 ? 16 : compression == 4 ? 32 : 1;
     std::vector<int> chan_words(chans.size());
     for (size_t c = 0; c < chans.size(); ++c) chan_words[c] = chans[c].type == 1 ? 1 : 2;
-    const size_t nblocks = (size_t)((H + lines_per_block - 1) / lines_per_block);
+    const size_t ntx = tiled ? (size_t)((W + tile_w - 1) / tile_w) : 1, nty = tiled ? (size_t)((H + tile_h - 1) / tile_h) : 1;
+    const size_t nblocks = tiled ? ntx * nty : (size_t)((H + lines_per_block - 1) / lines_per_block);
+    if (nblocks > file.size() / 8) { err = "exr: offset table larger than the file"; return false; }
     std::vector<uint64_t> offsets(nblocks);
     for (auto &o : offsets) o = r.u64();
     if (!r.ok) { err = "exr: truncated offset table"; return false; }
@@ -197,19 +245,35 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
         std::vector<uint8_t> tmp, raw;
         if (offsets[b] + 8 > file.size()) { err = "exr: chunk offset beyond end of file"; return false; }
         Reader c{file.data() + offsets[b], file.data() + file.size()};
-        const int32_t y = c.i32(), size = c.i32();
-        if (!c.ok || size < 0 || !c.need((size_t)size)) { err = "exr: truncated chunk"; return false; }
-        const long y0 = (long)y - dw[1];
-        if (y0 < 0 || y0 >= H) { err = "exr: chunk outside the data window"; return false; }
-        const long nl = std::min<long>(lines_per_block, H - y0);
+        long x0 = 0, y0, bw = W, nl;
+        int32_t size;
+        if (tiled) {   // tile chunk: tile coordinates, level (0,0), size
+            const int32_t tx = c.i32(), ty = c.i32(), lx = c.i32(), ly = c.i32();
+            size = c.i32();
+            if (!c.ok || size < 0 || !c.need((size_t)size)) { err = "exr: truncated tile chunk"; return false; }
+            if (lx != 0 || ly != 0 || tx < 0 || ty < 0 || (size_t)tx >= ntx || (size_t)ty >= nty) { err = "exr: tile outside the level-0 grid"; return false; }
+            x0 = (long)tx * tile_w; y0 = (long)ty * tile_h;
+            bw = std::min<long>(tile_w, W - x0); nl = std::min<long>(tile_h, H - y0);
+        } else {
+            const int32_t y = c.i32();
+            size = c.i32();
+            if (!c.ok || size < 0 || !c.need((size_t)size)) { err = "exr: truncated chunk"; return false; }
+            y0 = (long)y - dw[1];
+            if (y0 < 0 || y0 >= H) { err = "exr: chunk outside the data window"; return false; }
+            nl = std::min<long>(lines_per_block, H - y0);
+        }
+        const size_t line_bytes = px_bytes * (size_t)bw;
         const size_t expect = line_bytes * (size_t)nl;
         const uint8_t *data;
         if ((size_t)size == expect || compression == 0) {
             if ((size_t)size != expect) { err = "exr: raw chunk has the wrong size"; return false; }
             data = c.p;                                      // stored uncompressed
         } else if (compression == 4) {
-            if (!piz_decode_block(c.p, (size_t)size, (int)W, (int)nl, chan_words, raw, err)) return false;
+            if (!piz_decode_block(c.p, (size_t)size, (int)bw, (int)nl, chan_words, raw, err)) return false;
             if (raw.size() != expect) { err = "exr: PIZ chunk decodes to the wrong size"; return false; }
+            data = raw.data();
+        } else if (compression == 5) {
+            if (!pxr24_decode(c.p, (size_t)size, bw, nl, types, raw, err)) return false;
             data = raw.data();
         } else {
             tmp.resize(expect);
@@ -224,10 +288,10 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
         }
         for (long l = 0; l < nl; ++l) {
             const uint8_t *line = data + (size_t)l * line_bytes;
-            float *out = rgba.data() + (size_t)(y0 + l) * W * 4;
+            float *out = rgba.data() + ((size_t)(y0 + l) * W + (size_t)x0) * 4;
             auto read_ch = [&](int ch, int dst_lo, int dst_hi) {
-                const uint8_t *q = line + choff[ch];
-                for (long x = 0; x < W; ++x) {
+                const uint8_t *q = line + chpre[ch] * (size_t)bw;
+                for (long x = 0; x < bw; ++x) {
                     float v;
                     if (chans[ch].type == 1) { uint16_t hv; memcpy(&hv, q + 2 * x, 2); v = half_to_float(hv); }
                     else if (chans[ch].type == 2) memcpy(&v, q + 4 * x, 4);

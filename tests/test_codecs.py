@@ -258,11 +258,134 @@ def test_exr_unsupported_features_are_named(tmp_path):
         mid.load_image(tmp_path / "b44.exr")
     assert "B44" in str(e.value) and e.value.code == 5
     blob2 = bytearray(p.read_bytes())
-    blob2[5] |= 0x02                                          # tiled bit
+    blob2[5] |= 0x02                                          # tiled bit without a tiles attribute
     (tmp_path / "tiled.exr").write_bytes(bytes(blob2))
     with pytest.raises(mid.MidError) as e:
         mid.load_image(tmp_path / "tiled.exr")
-    assert "tiled" in str(e.value)
+    assert "tiles attribute" in str(e.value)
+    mip = _exr_tiled(8, 8, [("R", 2)], 0, np.zeros((8, 8, 1), np.float32), 4, 4, level_mode=1)
+    (tmp_path / "mip.exr").write_bytes(mip)
+    with pytest.raises(mid.MidError) as e:
+        mid.load_image(tmp_path / "mip.exr")
+    assert "ONE_LEVEL" in str(e.value)
+
+
+def _zip_block(raw):
+    t = np.frombuffer(raw, np.uint8)
+    t = np.concatenate([t[0::2], t[1::2]])
+    d = t.astype(np.int16)
+    d[1:] = (d[1:] - d[:-1] + 128) & 255
+    z = zlib.compress(d.astype(np.uint8).tobytes())
+    return z if len(z) < len(raw) else raw
+
+
+def _exr_tiled(w, h, channels, compression, px, tw, th, level_mode=0, shuffle=None):
+    """Hand-built single-level tiled EXR (independent of the reader): px[y, x, c] in channel order, NONE or ZIP tiles;
+    tile chunks = tileX, tileY, levelX, levelY, size, data (per line: channel after channel)."""
+    def attr(name, typ, val):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(val)) + val
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", t, 0, 0, 0, 0, 1, 1) for n, t in channels) + b"\0"
+    dw = (0, 0, w - 1, h - 1)
+    hdr = struct.pack("<ii", 20000630, 2 | 0x200)
+    hdr += attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression]))
+    hdr += attr("dataWindow", "box2i", struct.pack("<4i", *dw)) + attr("displayWindow", "box2i", struct.pack("<4i", *dw))
+    hdr += attr("lineOrder", "lineOrder", bytes([0])) + attr("pixelAspectRatio", "float", struct.pack("<f", 1))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<2f", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1))
+    hdr += attr("tiles", "tiledesc", struct.pack("<IIB", tw, th, level_mode)) + b"\0"
+    tiles = []
+    for ty in range((h + th - 1) // th):
+        for tx in range((w + tw - 1) // tw):
+            sub = px[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
+            raw = b"".join(np.ascontiguousarray(sub[y, :, c]).tobytes() for y in range(sub.shape[0]) for c in range(len(channels)))
+            tiles.append((tx, ty, _zip_block(raw) if compression == 3 else raw))
+    order = list(range(len(tiles)))
+    if shuffle is not None:
+        shuffle.shuffle(order)                                # tiles may sit in the file in any order
+    pos = len(hdr) + 8 * len(tiles)
+    offsets, body = [0] * len(tiles), b""
+    for i in order:
+        offsets[i] = pos + len(body)
+        tx, ty, payload = tiles[i]
+        body += struct.pack("<iiiii", tx, ty, 0, 0, len(payload)) + payload
+    return hdr + b"".join(struct.pack("<Q", o) for o in offsets) + body
+
+
+@pytest.mark.parametrize("compression", [0, 3])
+@pytest.mark.parametrize("ptype,tile", [(2, (16, 16)), (1, (32, 8)), (2, (64, 64))])
+def test_exr_tiled_one_level(tmp_path, compression, ptype, tile):
+    rng = np.random.default_rng(compression + ptype)
+    h, w = 45, 70                                             # ragged edge tiles in both directions
+    dt = np.float16 if ptype == 1 else np.float32
+    px = (rng.random((h, w, 4)) * 4).astype(dt)               # stored channel order A,B,G,R
+    chans = [("A", ptype), ("B", ptype), ("G", ptype), ("R", ptype)]
+    p = tmp_path / "tiled.exr"
+    p.write_bytes(_exr_tiled(w, h, chans, compression, px, tile[0], tile[1], shuffle=rng))
+    got = mid.load_image(p)
+    assert got.shape == (h, w, 4)
+    assert np.array_equal(got, px[..., ::-1].astype(np.float32))
+
+
+def _pxr24_block(lines, channels, w):
+    """ImfPxr24Compressor restated independently: per line and channel, delta-coded values split into byte planes
+    (MSB plane first): HALF 2 planes, FLOAT 3 planes of the float24 = top 24 bits (rounded), UINT 4 planes; then deflate."""
+    out = bytearray()
+    for ln in lines:
+        for name, t in channels:
+            if t == 1:
+                v = np.frombuffer(ln[name], np.uint16).astype(np.uint32)
+                d = (v - np.concatenate([[0], v[:-1]])).astype(np.uint32)
+                out += ((d >> 8) & 255).astype(np.uint8).tobytes() + (d & 255).astype(np.uint8).tobytes()
+            elif t == 2:
+                v24 = np.frombuffer(ln[name], np.uint32) >> 8                      # caller passes floats whose low 8 bits are zero
+                d = (v24 - np.concatenate([[0], v24[:-1]])).astype(np.uint32)
+                out += ((d >> 16) & 255).astype(np.uint8).tobytes() + ((d >> 8) & 255).astype(np.uint8).tobytes() + (d & 255).astype(np.uint8).tobytes()
+            else:
+                v = np.frombuffer(ln[name], np.uint32)
+                d = (v - np.concatenate([[0], v[:-1]])).astype(np.uint32)
+                out += b"".join(((d >> sh) & 255).astype(np.uint8).tobytes() for sh in (24, 16, 8, 0))
+    return zlib.compress(bytes(out))
+
+
+def test_exr_pxr24_reader(tmp_path):
+    """PXR24 scanline file with HALF, FLOAT and UINT channels (FLOAT values pre-truncated to 24 bits, so the lossy codec
+    is exact on them); 16-line blocks, ragged last block, non-zero data window origin."""
+    rng = np.random.default_rng(24)
+    h, w = 37, 53
+    f = (rng.standard_normal((h, w, 3)) * 3).astype(np.float32)
+    f = (f.view(np.uint32) & np.uint32(0xffffff00)).view(np.float32)               # representable in float24
+    a = rng.random((h, w)).astype(np.float16)
+    chans = [("A", 1), ("B", 2), ("G", 2), ("R", 2)]
+    lines = [{"A": a[y].tobytes(), "B": f[y, :, 2].tobytes(), "G": f[y, :, 1].tobytes(), "R": f[y, :, 0].tobytes()} for y in range(h)]
+    blocks = [(y0 - 2, _pxr24_block(lines[y0:y0 + 16], chans, w)) for y0 in range(0, h, 16)]
+    blob = bytearray(_exr(w, h, chans, 0, lines, None, data_window=(3, -2, 3 + w - 1, -2 + h - 1)))
+    i = blob.index(b"compression\0compression\0") + 24 + 4
+    blob[i] = 5
+    hdr_end = blob.index(b"screenWindowWidth\0float\0") + 24 + 4 + 4 + 1
+    pos = hdr_end + 8 * len(blocks)
+    body, offs = b"", []
+    for y, payload in blocks:
+        offs.append(pos + len(body))
+        body += struct.pack("<ii", y, len(payload)) + payload
+    p = tmp_path / "pxr24.exr"
+    p.write_bytes(bytes(blob[:hdr_end]) + b"".join(struct.pack("<Q", o) for o in offs) + body)
+    got = mid.load_image(p)
+    assert got.shape == (h, w, 4)
+    assert np.array_equal(got[..., :3], f) and np.array_equal(got[..., 3], a.astype(np.float32))
+    # UINT channel + corruption
+    u = rng.integers(0, 2 ** 32 - 1, (5, 9), dtype=np.uint64).astype(np.uint32)
+    ul = [{"Y": u[y].tobytes()} for y in range(5)]
+    blob = bytearray(_exr(9, 5, [("Y", 0)], 0, ul, None))
+    blob[blob.index(b"compression\0compression\0") + 24 + 4] = 5
+    hdr_end = blob.index(b"screenWindowWidth\0float\0") + 24 + 4 + 4 + 1
+    payload = _pxr24_block(ul, [("Y", 0)], 9)
+    q = tmp_path / "pxr24u.exr"
+    q.write_bytes(bytes(blob[:hdr_end]) + struct.pack("<Q", hdr_end + 8) + struct.pack("<ii", 0, len(payload)) + payload)
+    assert np.array_equal(mid.load_image(q)[..., 0], u.astype(np.float32))
+    bad = bytearray(q.read_bytes())
+    bad[-3] ^= 0x55
+    q.write_bytes(bytes(bad))
+    with pytest.raises(mid.MidError):
+        mid.load_image(q)
 
 
 def test_truncated_and_corrupt_files_are_errors_not_crashes(tmp_path):
@@ -314,6 +437,23 @@ def test_sanitizer_sweep(tmp_path):
         f = tmp_path / name
         f.write_bytes(_exr(px.shape[1], px.shape[0], chans, 4, lines, None))
         extra.append(str(f))
+    # a ZIP tiled file and a PXR24 file (truncations and byte flips of both go through the sanitizer build too)
+    tpx = (rng.random((21, 30, 4)) * 2).astype(np.float32)
+    ft = tmp_path / "s_tiled.exr"
+    ft.write_bytes(_exr_tiled(30, 21, [("A", 2), ("B", 2), ("G", 2), ("R", 2)], 3, tpx, 16, 8))
+    extra.append(str(ft))
+    hp = (rng.random((20, 11)) * 3).astype(np.float16)
+    pl = [{"Y": hp[y].tobytes()} for y in range(20)]
+    blob = bytearray(_exr(11, 20, [("Y", 1)], 0, pl, None))
+    blob[blob.index(b"compression\0compression\0") + 24 + 4] = 5
+    hdr_end = blob.index(b"screenWindowWidth\0float\0") + 24 + 4 + 4 + 1
+    pay = [_pxr24_block(pl[y0:y0 + 16], [("Y", 1)], 11) for y0 in (0, 16)]
+    o0 = hdr_end + 16
+    fp = tmp_path / "s_pxr24.exr"
+    fp.write_bytes(bytes(blob[:hdr_end]) + struct.pack("<QQ", o0, o0 + 8 + len(pay[0])) +
+                   struct.pack("<ii", 0, len(pay[0])) + pay[0] + struct.pack("<ii", 16, len(pay[1])) + pay[1])
+    assert np.array_equal(mid.load_image(fp)[..., 0], hp.astype(np.float32))
+    extra.append(str(fp))
     r = subprocess.run([str(exe)] + extra, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "sanitizer sweep done" in r.stdout

@@ -121,7 +121,7 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
         // event (inputs, ring-slot reuse, output-slot reuse), so the tail of one launch -- 1156 workgroups on 512
         // slots leave the last round a quarter full -- overlaps the head of the next instead of idling the CUs.
         // (measured: one kernel stream 2385, two 2575, three 1892, four 1652 Mpixel/s; giving the second stream a
-        // lower or higher priority than the first: 2410-2430)
+        // lower or higher priority than the first: 2410-2430; splitting every download over two copy streams: 1860)
         hipStream_t cs = overlap && (bi & 1) ? ctx->compute2 : ctx->compute;
         MID_HIP(hipStreamWaitEvent(cs, up1.ev[need - f_lo], 0));
         if (bi >= DEPTH) MID_HIP(hipStreamWaitEvent(cs, d1.ev[bi - DEPTH], 0));

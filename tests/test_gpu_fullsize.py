@@ -102,3 +102,46 @@ def test_u8_round_trip_fullsize(ctx):
     f = ctx.unpack_u8(u8, 0)
     assert np.array_equal(ctx.pack_u8(f), u8)
     assert int(f.view(np.uint32).sum(dtype=np.uint64)) == int(oracle.unpack_u8(u8, 0).view(np.uint32).sum(dtype=np.uint64))
+
+
+def test_bilateral_scale_covariance_fullsize(ctx, frame):
+    """bilateral(a*I; sigma_c*a) == a*bilateral(I; sigma_c) for a power of two a: every product and difference scales
+    exactly, the exponent argument is unchanged -> identical bits up to the final scale."""
+    a = ctx.bilateral(frame, 8, 2.0, 0.2)
+    b = ctx.bilateral(frame * np.float32(4.0), 8, 2.0, 0.8)
+    assert rel_err(b, a * np.float32(4.0)) < 2e-6
+    # alpha is carried like colour (bialteral.comp:67,72): scaled too
+    assert rel_err(b[..., 3], a[..., 3] * 4.0) < 2e-6
+
+
+def test_nlm_limits_of_the_filtering_parameter_fullsize(ctx, frame):
+    """h -> 0: only the zero offset keeps weight 1 (d = 0), so out = I / 1.001 (the 0.001 norm bias, nonlocal.comp:32);
+    h -> large: every weight -> 1, so out = (21x21 box mean of I) * 441/441.001 in the interior."""
+    t = (frame * 0.25).astype(np.float32)
+    cfg = dict(search=(-10, 11), patch=(-3, 4))
+    tiny = ctx.nlm_temporal([t], k=0, hparam=1e-3, **cfg)[0]
+    assert rel_err(tiny * np.float32(1.001), t) < 2e-6
+    big = ctx.nlm_temporal([t], k=0, hparam=1e4, **cfg)[0]
+    # box mean over offsets [-10, 11) in both axes, via a float64 summed-area table
+    sat = np.zeros((H + 1, W + 1, 4), np.float64)
+    sat[1:, 1:] = t.astype(np.float64).cumsum(0).cumsum(1)
+    ys, xs = np.arange(10, H - 10), np.arange(10, W - 10)
+    box = (sat[ys[:, None] + 11, xs[None, :] + 11] - sat[ys[:, None] - 10, xs[None, :] + 11]
+           - sat[ys[:, None] + 11, xs[None, :] - 10] + sat[ys[:, None] - 10, xs[None, :] - 10]) / 441.001
+    assert rel_err(big[10:-10, 10:-10], box) < 2e-5
+
+
+def test_translation_equivariance_away_from_the_borders(ctx, frame):
+    """Shifting the frame shifts the result: tiles, strips and wave seams land on different pixels, so this catches any
+    dependence on the position inside a tile beyond rounding."""
+    t = (frame * 0.25).astype(np.float32)
+    dy, dx = 5, 37
+    sh = np.roll(t, (dy, dx), axis=(0, 1))
+    cfg = dict(search=(-10, 11), patch=(-3, 4))
+    a = ctx.nlm_temporal([t], k=0, **cfg)[0]
+    b = ctx.nlm_temporal([sh], k=0, **cfg)[0]
+    m = 13 + max(dy, dx)
+    assert rel_err(b[m:-m, m:-m], np.roll(a, (dy, dx), axis=(0, 1))[m:-m, m:-m]) < 2e-6
+    ba = ctx.bilateral(t, 8, 2.0, 0.2)
+    bb = ctx.bilateral(sh, 8, 2.0, 0.2)
+    assert np.array_equal(bb[m:-m, m:-m], np.roll(ba, (dy, dx), axis=(0, 1))[m:-m, m:-m]), "bilateral taps are summed in tap order: bit-identical"

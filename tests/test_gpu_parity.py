@@ -373,3 +373,25 @@ def test_runtime_range_kernel_small_then_large_window(ctx):
         got = ctx.nlm_accum(t, nb, Z(40, 70), 0.5, search=search, patch=(-2, 3))
         ref = oracle.nlm_accum(t, nb, Z(40, 70), 0.5, search=search, patch=(-2, 3))
         assert rel_err(got[..., :5], ref[..., :5]) < 5e-5, search
+
+
+@pytest.mark.parametrize("R", list(range(1, 25)))
+def test_bilateral_every_radius(ctx, R):
+    """radius is a run-time parameter of the ABI (1..24): tuned tiles, the run-time-radius tiled kernel and the
+    per-pixel fallback between them must cover the whole range."""
+    rng = np.random.default_rng(100 + R)
+    img = synth_hdr(rng, 30, 70)
+    for layout, f in (("texture", oracle.bilateral_texture), ("linear", oracle.bilateral_linear)):
+        assert rel_err(ctx.bilateral(img, R, 1.0 + R / 4, 0.3, layout), f(img, R, 1.0 + R / 4, 0.3)) < BIL_TOL, (R, layout)
+
+
+@pytest.mark.parametrize("search,patch", [((-5, 9), (-3, 4)), ((-12, 13), (-2, 3)), ((0, 1), (-3, 3)), ((-1, 2), (-4, 5)),
+                                          ((-16, 17), (-1, 2)), ((-3, 1), (-1, 2)), ((-9, 10), (0, 1)), ((-2, 3), (-5, 6))])
+def test_nlm_unusual_windows(ctx, search, patch):
+    """Asymmetric and degenerate search ranges, every patch size the run-time-range kernel knows and two it does not
+    (1x1 and 11x11 fall to the per-pixel kernel)."""
+    rng = np.random.default_rng(abs(search[0]) * 31 + patch[1])
+    t, nb = synth_hdr(rng, 29, 71) * 0.3, synth_hdr(rng, 29, 71) * 0.3
+    got = ctx.nlm_accum(t, nb, Z(29, 71), 0.45, search, patch)
+    ref = oracle.nlm_accum(t, nb, Z(29, 71), 0.45, search, patch)
+    assert rel_err(got, ref) < 5e-5, (search, patch)

@@ -49,3 +49,28 @@ def test_sequence_u8_output_is_the_references_readback_conversion(ctx, k, n):
     # a sub-range, as a frame-block shard would ask for it
     part, _ = ctx.sequence_nlm(frames, k=k, first=1, count=2, out_u8=True)
     assert all(np.array_equal(a, oracle.pack_u8(b)) for a, b in zip(part, f32[1:3]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7])
+def test_multiframe_mode_matches_the_dispatch_sequence(ctx, n):
+    """mid_nlm_multiframe (the reference's literal mode: one target, n neighbour frames, one accumulate per frame, then
+    normalize; src/main.cpp:1539-1606) with and without overlap == mid_nlm_accum x n + mid_normalize, bit for bit,
+    for HDR and LDR frames; and it matches the oracle."""
+    from conftest import synth_ldr
+    rng = np.random.default_rng(50 + n)
+    for ldr in (False, True):
+        frames = [synth_ldr(rng, 35, 67) if ldr else synth_hdr(rng, 35, 67) * 0.3 for _ in range(n)]
+        target = frames[0]
+        W = np.zeros((35, 67, 8), np.float32)
+        for f in frames:
+            W = ctx.nlm_accum(target, f, W, 0.5, (-7, 7), (-3, 3))
+        want = ctx.normalize(W)
+        for overlap in (True, False):
+            got, (wall, kern, copy) = ctx.nlm_multiframe(target, frames, overlap=overlap)
+            assert np.array_equal(got, want), (ldr, overlap)
+            assert wall > 0 and kern > 0 and copy > 0
+        f32 = [oracle.unpack_u8(f, 0) if ldr else f for f in frames]
+        Wo = np.zeros((35, 67, 8), np.float32)
+        for f in f32:
+            Wo = oracle.nlm_accum(f32[0], f, Wo, 0.5, (-7, 7), (-3, 3))
+        assert rel_err(want, oracle.normalize(Wo)) < 2e-5

@@ -66,3 +66,12 @@ def test_product_package_never_imports_the_oracle():
     assert bench.count("import oracle") == 1
     before = bench[:bench.index("import oracle")]
     assert before.rsplit("\ndef ", 1)[1].startswith("cpu_baseline("), "bench.py may use the oracle only inside cpu_baseline()"
+
+
+def test_missing_library_is_an_import_error_not_a_fallback(tmp_path):
+    """No .so, no product: importing the package must fail loudly (there is no CPU or PyTorch fallback path)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MID_LIB_PATH=str(tmp_path / "absent" / "libmi_denoise.so"))
+    r = subprocess.run([sys.executable, "-c", "import image_denoising_filter_amd"], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "ImportError" in r.stderr and "no CPU or PyTorch fallback" in r.stderr

@@ -325,9 +325,10 @@ def test_frame_larger_than_2_gib(ctx):
 
 # ---- randomized differential sweep ------------------------------------------------------------------
 def test_random_parameter_sweep_against_oracle(ctx):
-    """40 random (size, format, operator, parameter) draws, every one compared with the oracle."""
-    rng = np.random.default_rng(2025)
-    for case in range(40):
+    """40 random (size, format, operator, parameter) draws, every one compared with the oracle.
+    (MID_SWEEP_CASES / MID_SWEEP_SEED lengthen or re-seed the sweep for a soak run.)"""
+    rng = np.random.default_rng(int(os.environ.get("MID_SWEEP_SEED", "2025")))
+    for case in range(int(os.environ.get("MID_SWEEP_CASES", "40"))):
         h, w = int(rng.integers(1, 90)), int(rng.integers(1, 150))
         ldr = bool(rng.integers(0, 2))
         img = synth_ldr(rng, h, w) if ldr else (synth_hdr(rng, h, w) * float(rng.uniform(0.1, 1.0))).astype(np.float32)

@@ -65,6 +65,8 @@ _SIGNATURES = {
     "mid_free": (ctypes.c_int, [_P, _P]),
     "mid_alloc_host": (ctypes.c_int, [_P, ctypes.c_size_t, c_void_pp]),
     "mid_free_host": (ctypes.c_int, [_P, _P]),
+    "mid_host_register": (ctypes.c_int, [_P, _P, ctypes.c_size_t]),
+    "mid_host_unregister": (ctypes.c_int, [_P, _P]),
     "mid_memcpy_h2d": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
     "mid_memcpy_d2h": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
     "mid_memset": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_size_t, _P]),

@@ -120,6 +120,24 @@ extern "C" int mid_free_host(mid_ctx *ctx, void *hptr)
     return MID_OK;
 }
 
+extern "C" int mid_host_register(mid_ctx *ctx, void *hptr, size_t bytes)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(hptr && bytes > 0, "host_register: bad argument");
+    MID_HIP(hipHostRegister(hptr, bytes, hipHostRegisterPortable));   // pinned for every device of the process
+    return MID_OK;
+}
+
+extern "C" int mid_host_unregister(mid_ctx *ctx, void *hptr)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(hptr, "host_unregister: NULL pointer");
+    MID_HIP(hipHostUnregister(hptr));
+    return MID_OK;
+}
+
 extern "C" int mid_memcpy_h2d(mid_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream)
 {
     Bind b(ctx, stream);

@@ -105,6 +105,11 @@ int mid_alloc(mid_ctx *ctx, size_t bytes, void **dptr);              /* CreateWr
 int mid_free(mid_ctx *ctx, void *dptr);
 int mid_alloc_host(mid_ctx *ctx, size_t bytes, void **hptr);         /* pinned staging (CreateStagingBuffer/CreateDynamicBuffer) */
 int mid_free_host(mid_ctx *ctx, void *hptr);
+/* Pin memory the caller already owns (a decoded frame in a std::vector, say) so that the pipeline can DMA it directly
+ * instead of going through a staging copy (the pinning holds for every device of the process); undo with
+ * mid_host_unregister before the memory is freed and after every copy that uses it has completed. */
+int mid_host_register(mid_ctx *ctx, void *hptr, size_t bytes);
+int mid_host_unregister(mid_ctx *ctx, void *hptr);
 int mid_memcpy_h2d(mid_ctx *ctx, void *dst, const void *src_host, size_t bytes, void *stream);  /* LoadImageDataToBuffer + copy-to-texture, src/main.cpp:1105-1142,990-1076 */
 int mid_memcpy_d2h(mid_ctx *ctx, void *dst_host, const void *src, size_t bytes, void *stream);  /* vkCmdCopyBuffer to staging + GetImageFromGPU, src/main.cpp:835-840,91-123 */
 int mid_memset(mid_ctx *ctx, void *dst, int value, size_t bytes, void *stream);                 /* the reference never clears its weight buffer; callers of *_accum must */

@@ -22,3 +22,8 @@ for ext in ("png", "exr"):
     print(f"==== {ext}: exit {r.returncode}, wall {time.time() - t0:.2f} s")
     print("\n".join(l for l in r.stdout.splitlines() if "time" in l or "Running" in l))
     print(sorted(f for f in os.listdir(os.path.join(root, ext)) if f.startswith("output")))
+    t0 = time.time()
+    r = subprocess.run([os.path.join(os.path.dirname(mid.LIB_PATH), "mi_denoise"), os.path.join(d, f"Animation01_X_0000.{ext}"), "--animation",
+                        "--temporal-k", "1", "--outdir", os.path.join(root, ext)], capture_output=True, text=True)
+    print(f"==== {ext} --animation: exit {r.returncode}, wall {time.time() - t0:.2f} s")
+    print("\n".join(l for l in r.stdout.splitlines() if "Mpixel" in l or "time" in l))

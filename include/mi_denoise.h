@@ -105,9 +105,12 @@ int mid_alloc(mid_ctx *ctx, size_t bytes, void **dptr);              /* CreateWr
 int mid_free(mid_ctx *ctx, void *dptr);
 int mid_alloc_host(mid_ctx *ctx, size_t bytes, void **hptr);         /* pinned staging (CreateStagingBuffer/CreateDynamicBuffer) */
 int mid_free_host(mid_ctx *ctx, void *hptr);
-/* Pin memory the caller already owns (a decoded frame in a std::vector, say) so that the pipeline can DMA it directly
- * instead of going through a staging copy (the pinning holds for every device of the process); undo with
- * mid_host_unregister before the memory is freed and after every copy that uses it has completed. */
+/* Pin memory the caller already owns (a decoded frame in a std::vector, say) so that copies from/to it are truly
+ * asynchronous (the pinning holds for every device of the process); undo with mid_host_unregister before the memory is
+ * freed and after every copy that uses it has completed.  Measured on MI355X, 16 x 1080p RGBA32F through
+ * mid_sequence_nlm: buffers from mid_alloc_host 12.8 ms, pageable memory (HIP stages it) 20.2 ms, memory registered in
+ * place 25.1 ms (+6 ms to register) -- so decode into mid_alloc_host buffers when throughput matters, and register in
+ * place only when the calling thread must not block in the copy. */
 int mid_host_register(mid_ctx *ctx, void *hptr, size_t bytes);
 int mid_host_unregister(mid_ctx *ctx, void *hptr);
 int mid_memcpy_h2d(mid_ctx *ctx, void *dst, const void *src_host, size_t bytes, void *stream);  /* LoadImageDataToBuffer + copy-to-texture, src/main.cpp:1105-1142,990-1076 */

@@ -298,19 +298,9 @@ public:
         std::vector<std::vector<unsigned char>> out8(hdr ? 0 : n, std::vector<unsigned char>((size_t)w * h * 4));
         for (int i = 0; i < n; ++i) in[i] = frames[i].bytes.data();
         const int G = std::max(1, std::min(opt.gpus, n));
-        // Pin every frame and every output in place, once, for all devices: the pipelines then DMA them directly
-        // (pageable memory would be staged and the overlap lost).  Best effort -- an unpinned buffer still works.
-        struct Pins {
-            mid_ctx *c = nullptr; std::vector<void *> v;
-            void add(void *q, size_t bytes) { if (c && mid_host_register(c, q, bytes) == MID_OK) v.push_back(q); }
-            ~Pins() { for (void *q : v) mid_host_unregister(c, q); if (c) mid_ctx_destroy(c); }
-        } pins;
-        if (mid_ctx_create(opt.device, &pins.c) != MID_OK) pins.c = nullptr;
-        for (int i = 0; i < n; ++i) {
-            pins.add(frames[i].bytes.data(), frames[i].bytes.size());
-            if (hdr) pins.add(out[i].data(), out[i].size() * sizeof(Pixel));
-            else pins.add(out8[i].data(), out8[i].size());
-        }
+        // Frames stay in pageable memory: HIP stages such copies itself, and that measured faster than pinning the
+        // vectors in place (20.2 vs 25.1 ms per 16 x 1080p RGBA32F; buffers from mid_alloc_host reach 12.8 ms but would
+        // need the decoders to write into them).
         std::vector<std::string> errors(G);
         std::vector<float> kern(G, 0.f), copy(G, 0.f);
         std::vector<std::thread> workers;

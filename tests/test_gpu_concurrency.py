@@ -105,3 +105,28 @@ def test_caller_stream_orders_after_the_callers_own_work(ctx):
     assert np.array_equal(got_b.numpy(), want_b)
     for g, r in zip(got_n, want_n):
         assert np.array_equal(g.numpy(), r)
+
+
+def test_no_device_memory_is_leaked_by_the_entry_points(ctx):
+    """The library owns no caller-visible state beyond a context: after many pipeline / operator calls and the release of
+    the caller's buffers, free device memory is back where it started (allocator caches of torch are not involved:
+    the NumPy-level operators use mid_alloc / mid_free)."""
+    import torch
+    rng = np.random.default_rng(81)
+    frames = [synth_hdr(rng, 120, 200) * 0.3 for _ in range(5)]
+
+    def free_bytes():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0]
+
+    ctx.sequence_nlm(frames, k=1)                         # warm-up: code objects, streams, first allocations
+    before = free_bytes()
+    for i in range(25):
+        ctx.sequence_nlm(frames, k=i % 3, overlap=bool(i % 2), out_u8=False)
+        ctx.nlm_multiframe(frames[0], frames[:3])
+        ctx.bilateral(frames[0], 8, 2.0, 0.2)
+        ctx.bilateral_layers(frames[0], [np.zeros((120, 200, 4), np.uint8)] * 2, 4)
+        with mid.Context(0) as c2:
+            c2.nlm_temporal(frames[:2], k=1)
+    after = free_bytes()
+    assert before - after < 8 << 20, f"{(before - after) >> 20} MiB of device memory not returned"

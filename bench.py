@@ -37,9 +37,10 @@ BIL_FLOP_PER_PX = 20 * 17 * 17            # 5,780 at r=8
 BIL_BYTES_PER_PX = 32
 PEAK_FP32_TFLOPS = 157.3                  # MI355X_MICROARCH.md: fp32 vector = dense f32 MFMA peak
 PEAK_HBM_GBS = 8000.0
+SEQ_FRAMES = 64                           # BASELINE configs[4]: one 64-frame animation, temporal +-2
 
 
-def synth_frames(n, seed, device):
+def synth_frames(n, seed, device, shift=0):
     """Seeded 'path-tracer-like' HDR frames: piecewise-smooth radiance with
     highlights times per-pixel Gamma(4) noise, alpha = 1.  Generated on the GPU with torch."""
     g = torch.Generator(device=device)
@@ -54,25 +55,29 @@ def synth_frames(n, seed, device):
         # Gamma(4, 1/4) as the mean of 4 exponentials; pan 2 px per frame
         u = torch.rand((4, H, W, 1), generator=g, device=device).clamp_min(1e-7)
         noise = (-torch.log(u)).mean(0)
-        rad = torch.roll(base + hl, shifts=2 * i, dims=1) * noise
+        rad = torch.roll(base + hl, shifts=2 * i + shift, dims=1) * noise
         out.append(torch.cat([rad, torch.ones((H, W, 1), device=device)], -1).contiguous())
     return out
 
 
 def load_traffic(frames_per_launch):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
+    """(HBM bytes per launch, where that figure comes from).  PMC counters cannot be read from inside an
+    un-profiled run, so the figure is the one measured by the committed rocprofv3 `--pmc` passes of this same
+    command (profiles/*_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); `traffic_source` in the JSON
+    line says so, with the file and its date.  (None, reason) when no profile matches the launch shape."""
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not cands:
-        return None
+        return None, "no profiles/r*_traffic.json"
     try:
         t = json.load(open(cands[-1]))
         if t.get("algorithmic_bytes_per_launch") != frames_per_launch * NPIX * NLM_BYTES_PER_PX:
-            return None          # measured for a different launch shape
-        return round(t["traffic_bytes_per_launch"])
-    except Exception:
-        return None
+            return None, f"{os.path.basename(cands[-1])} was measured for a different launch shape"
+        when = t.get("date") or time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(cands[-1])))
+        return round(t["traffic_bytes_per_launch"]), (f"profiles/{os.path.basename(cands[-1])} ({when}): rocprofv3 --pmc FETCH_SIZE / "
+                                                     "WRITE_SIZE passes of this command, read back -- not measured in this run")
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable profile: {e}"
 
 
 class Timers:
@@ -179,9 +184,15 @@ def dry_run(args):
     max-over-ranks, the temporal step with its overlapped halo exchange, one JSON line from rank 0."""
     from image_denoising_filter_amd import sharding
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        world = dist.get_world_size()
+    if os.environ.get("MID_BENCH_TEST_FAIL_RANK") == str(rank):      # tests/test_bench_dryrun.py: a rank that dies
+        os._exit(7)
     h, w, F, k = 12, 20, args.frames, 2
     g = torch.Generator().manual_seed(100 + rank)
     frames = [torch.rand((h, w, 4), generator=g) for _ in range(F)]
@@ -225,9 +236,68 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` started plainly (no torchrun, WORLD_SIZE unset): this process becomes a pure
+    launcher.  It never touches the GPU (no torch.cuda call, no HIP call, no exec): it starts N fresh children
+    of this same script -- one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their environment, rendezvous on
+    127.0.0.1 -- relays rank 0's single JSON line on stdout (the other ranks' stdout goes to stderr) and
+    returns non-zero if any rank fails; when one rank dies the others are terminated (by PID) so that a
+    collective waiting for the dead rank cannot hang the run."""
+    import subprocess
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py launcher: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    json_lines = [l for l in out0 if l.startswith("{")]
+    for l in out0:
+        (sys.stdout if l.startswith("{") else sys.stderr).write(l)
+    sys.stdout.flush()
+    if rc == 0 and len(json_lines) != 1:
+        print(f"bench.py launcher: expected one JSON line from rank 0, got {len(json_lines)}", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap = argparse.ArgumentParser(
+        description="Headline benchmark.  N > 1: either start it under torch.distributed.run (one rank per GPU, as the "
+                    "driver does) or plainly as `python bench.py --gpus N` -- it then launches its own N ranks.")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node to use, one process each; without RANK/WORLD_SIZE in the environment "
+                         "bench.py spawns the N ranks itself")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step")
@@ -240,6 +310,11 @@ def main():
                     help="CPU rehearsal of the multi-rank control flow (gloo, no kernels, tiny frames); "
                          "marks its JSON dry_run=true -- never a measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher above us: become one, BEFORE anything touches the GPU (see launch_ranks)
+        sys.exit(launch_ranks(args.gpus))
     if args.dry_run:
         return dry_run(args)
 
@@ -247,13 +322,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        # a launcher that disagrees with --gpus is a set-up error, not something to paper over with a 1-GPU number
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        world = dist.get_world_size()           # n_gpus is what the process group says, not what the flags say
 
     import image_denoising_filter_amd as mid
     from image_denoising_filter_amd import sharding
@@ -316,6 +393,7 @@ def main():
     value = world * F * args.steps * NPIX / 1e6 / elapsed
     px_per_launch = F * NPIX // launches_per_step
     avg_launch_s /= launches_per_step        # the timers bracket one step = launches_per_step back-to-back launches
+    traffic, traffic_source = load_traffic(F) if args.workload == "nlm" else (None, "not profiled for this workload")
     res = {
         "metric": metric,
         "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -325,12 +403,12 @@ def main():
                    "frames_per_gpu_per_step": F, "width": W, "height": H, "h": HPARAM,
                    "parallelism": f"frame-sharded x{world}, no data-path collective"},
         "roofline": {
-            "bound": "mfma", "achieved": round(flop_px * px_per_launch / avg_launch_s / 1e12, 3),
+            "bound": "mfma", "bound_actual": "valu", "achieved": round(flop_px * px_per_launch / avg_launch_s / 1e12, 3),
             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop_px * px_per_launch / avg_launch_s / 1e12 / PEAK_FP32_TFLOPS, 4),
-            "traffic": load_traffic(F) if args.workload == "nlm" else None,
+            "traffic": traffic, "traffic_source": traffic_source,
             "kernel": kernel, "avg_launch_ms": round(avg_launch_s * 1e3, 4),
-            "note": "compute roofline: the kernel is fp32-VALU bound and issues no MFMA; the peak is the fp32 "
+            "note": "compute roofline (`bound` keeps the contract's enum; bound_actual says what binds): the kernel is fp32-VALU bound and issues no MFMA; the peak is the fp32 "
                     "vector peak, which equals the dense f32 MFMA peak on gfx950 (157.3 TFLOP/s). Algorithmic "
                     f"flops = {flop_note} x px per launch.",
             "hbm": {"achieved_GBs": round(bytes_px * px_per_launch / avg_launch_s / 1e9, 1),
@@ -356,7 +434,7 @@ def main():
     def on_timeout():
         also["error"] = "extras did not finish within 300 s; line emitted by the watchdog"
         emit()
-        os._exit(0)
+        os._exit(3)             # the line is out, but a run whose extras hung is not a clean run
     watchdog = threading.Timer(300.0, on_timeout)
     watchdog.daemon = True
     watchdog.start()
@@ -428,36 +506,57 @@ def main():
         guarded("single_frame", extra_single_frame)
 
         def extra_temporal():
-            # temporal +-2 NLM over this rank's block, halo frames from the neighbours over RCCL
+            # BASELINE configs[4]: ONE 64-frame sequence, temporal +-2 NLM, contiguous frame blocks over the ranks
+            # (64/N frames each: strong scaling of a fixed job), halo frames from the neighbours over RCCL.
             k = 2
-            n_seq = world * F
+            n_seq = SEQ_FRAMES
             start, count = sharding.partition(n_seq, world)[rank]
+            # frame g of the sequence has seed 1000+g on every rank count, so the job is the same at every N
+            seq = [synth_frames(1, 1000 + g, device, shift=2 * g)[0] for g in range(start, start + count)]
+            souts = [torch.empty((H, W, 4), device=device, dtype=torch.float32) for _ in range(count)]
+            soptr = [o.data_ptr() for o in souts]
+            stats, ev = {}, [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
             def launch(fr, first, cnt, off):
-                ctx.nlm_temporal_dev([f.data_ptr() for f in fr], optr[off:off + cnt], W, H, HPARAM, SEARCH, PATCH,
+                ctx.nlm_temporal_dev([f.data_ptr() for f in fr], soptr[off:off + cnt], W, H, HPARAM, SEARCH, PATCH,
                                      k, first, cnt, mid.FMT_RGBA32F, stream)
+
+            hooks = {"stats": stats, "before_wait": lambda: ev[0].record(tstream), "after_wait": lambda: ev[1].record(tstream)}
 
             def temporal_step():
                 # halo isend/irecv posted first, interior frames filtered meanwhile, boundary frames after the wait
-                sharding.temporal_block_overlapped(launch, frames, n_seq, k)
+                sharding.temporal_block_overlapped(launch, seq, n_seq, k, hooks=hooks)
 
             temporal_step()
             torch.cuda.synchronize()
             barrier()
             t1 = time.perf_counter()
             reps = 3
+            held = 0.0
             for _ in range(reps):
                 temporal_step()
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                held += ev[0].elapsed_time(ev[1])
             barrier()
             te = (time.perf_counter() - t1) / reps
+            per_rank = [te, held / reps, float(stats.get("halo_bytes_recv", 0)), float(stats.get("halo_bytes_sent", 0))]
             if world > 1:
-                t = torch.tensor([te], device=device, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                te = float(t.item())
+                t = torch.tensor(per_rank, device=device, dtype=torch.float64)
+                allr = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(allr, t)
+                rows = [[float(x) for x in a.tolist()] for a in allr]
+            else:
+                rows = [per_rank]
+            te = max(r[0] for r in rows)
             also["temporal_nlm_k2"] = {"Mpixel/s_out": round(n_seq * NPIX / 1e6 / te, 1), "frames": n_seq,
-                                       "ms_per_sequence": round(te * 1e3, 3),
-                                       "halo": "RCCL isend/irecv of 2 frames per side, overlapped with the interior frames" if world > 1 else "none (1 rank)"}
+                                       "frames_per_rank": [c for _, c in sharding.partition(n_seq, world)],
+                                       "ms_per_sequence": round(te * 1e3, 3), "scaling": "strong (one 64-frame sequence)",
+                                       "halo_bytes_recv_per_rank": [int(r[2]) for r in rows],
+                                       "halo_bytes_sent_per_rank": [int(r[3]) for r in rows],
+                                       "halo_held_ms_per_rank": [round(r[1], 4) for r in rows],
+                                       "halo": ("RCCL isend/irecv of 2 frames per side, posted before the interior frames; held_ms = time "
+                                                "the launch stream sat between the last interior launch and the first boundary launch")
+                                               if world > 1 else "none (1 rank)"}
 
         guarded("temporal", extra_temporal)
 

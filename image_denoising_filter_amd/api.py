@@ -10,6 +10,7 @@ NumPy arrays are (h, w, 4): float32 = RGBA32F (.exr path), uint8 = RGBA8 (.png p
 WeightInfo buffers are float32 (h, w, 8): [wc.r, wc.g, wc.b, wc.a, normWeight, pad, pad, pad].
 """
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -65,11 +66,13 @@ class DeviceBuffer:
         p = ctypes.c_void_p()
         _check(lib.mid_alloc(ctx.handle, self.nbytes, ctypes.byref(p)), "mid_alloc")
         self.ptr = p.value
+        ctx._live.add(self)
 
     def free(self):
-        if self.ptr:
+        # a buffer that outlives its context was already released by Context.close() (ptr is None then)
+        if self.ptr and self.ctx.handle:
             lib.mid_free(self.ctx.handle, self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -93,6 +96,18 @@ def _img(a):
     return a
 
 
+def _same_frames(frames, what):
+    """Every frame of a sequence is read with frames[0]'s size and format: refuse anything else up front."""
+    frames = [_img(f) for f in frames]
+    if not frames:
+        raise ValueError(f"{what}: no frames")
+    _fmt_of(frames[0])
+    for i, f in enumerate(frames):
+        if f.shape != frames[0].shape or f.dtype != frames[0].dtype:
+            raise ValueError(f"{what}: frame {i} is {f.shape} {f.dtype}, frame 0 is {frames[0].shape} {frames[0].dtype}")
+    return frames
+
+
 class Context:
     """One device + its streams (mid_ctx).  Replaces the reference's Vulkan instance/device/queue."""
 
@@ -101,9 +116,12 @@ class Context:
         _check(lib.mid_ctx_create(int(device), ctypes.byref(h)), "mid_ctx_create")
         self.handle = h
         self.device = device
+        self._live = weakref.WeakSet()      # DeviceBuffers allocated through this context and not yet freed
 
     def close(self):
         if self.handle:
+            for buf in list(self._live):    # mid_free needs a live context: release what is still held, then the context
+                buf.free()
             lib.mid_ctx_destroy(self.handle)
             self.handle = None
 
@@ -159,6 +177,10 @@ class Context:
         _check(lib.mid_bilateral(self.handle, ctypes.byref(p), in_ptr, out_ptr, stream), "mid_bilateral")
 
     def nlm_temporal_dev(self, frame_ptrs, out_ptrs, w, h, hparam, search, patch, k, first, count, fmt, stream=None):
+        if not (0 <= first and count >= 1 and first + count <= len(frame_ptrs)):
+            raise ValueError(f"outputs [{first}, {first + count}) are not inside the {len(frame_ptrs)} frames given")
+        if len(out_ptrs) < count:
+            raise ValueError(f"{count} output frames asked for, only {len(out_ptrs)} output pointers given")
         p = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], fmt)
         fr = (ctypes.c_void_p * len(frame_ptrs))(*frame_ptrs)
         ou = (ctypes.c_void_p * len(out_ptrs))(*out_ptrs)
@@ -212,7 +234,7 @@ class Context:
 
     def nlm_temporal(self, frames, k=0, first=0, count=None, hparam=0.5, search=(-7, 7), patch=(-3, 3)):
         """Fused accumulate-over-neighbour-frames + normalize for `count` output frames."""
-        frames = [_img(f) for f in frames]
+        frames = _same_frames(frames, "nlm_temporal")
         count = len(frames) - first if count is None else count
         h, w = frames[0].shape[:2]
         d_fr = [self.upload(f) for f in frames]
@@ -247,7 +269,7 @@ class Context:
     def nlm_multiframe(self, target, frames, overlap=True, hparam=0.5, search=(-7, 7), patch=(-3, 3)):
         """The reference's multi-frame mode: one target, neighbour frames streamed (mid_nlm_multiframe)."""
         target = _img(target)
-        frames = [_img(f) for f in frames]
+        frames = _same_frames([target] + list(frames), "nlm_multiframe")[1:]
         h, w = target.shape[:2]
         out = np.empty((h, w, 4), np.float32)
         prm = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], _fmt_of(target))
@@ -262,9 +284,11 @@ class Context:
         """Host frames in, host frames out through the overlapped pipeline (mid_sequence_nlm_range[_u8]).
         out_u8: outputs converted to RGBA8 on the device like the reference's read-back (src/main.cpp:97-103).
         Returns (outputs for frames first..first+count-1, (wall_ms, kernel_ms, copy_ms))."""
-        frames = [_img(f) for f in frames]
+        frames = _same_frames(frames, "sequence_nlm")
         n = len(frames)
         count = n - first if count is None else count
+        if not (0 <= first and count >= 1 and first + count <= n):
+            raise ValueError(f"outputs [{first}, {first + count}) are not inside the {n} frames given")
         h, w = frames[0].shape[:2]
         fmt = _fmt_of(frames[0])
         in_bytes, out_bytes = frames[0].nbytes, w * h * (4 if out_u8 else 16)

@@ -243,7 +243,9 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
         std::string &err = errs[b];
         auto work = [&]() -> bool {
         std::vector<uint8_t> tmp, raw;
-        if (offsets[b] + 8 > file.size()) { err = "exr: chunk offset beyond end of file"; return false; }
+        // (written so that an offset near 2^64 cannot wrap the sum; 8 / 20 bytes = the scan-line / tile chunk header)
+        const size_t hdr = tiled ? 20 : 8;
+        if (offsets[b] > file.size() || file.size() - offsets[b] < hdr) { err = "exr: chunk offset beyond end of file"; return false; }
         Reader c{file.data() + offsets[b], file.data() + file.size()};
         long x0 = 0, y0, bw = W, nl;
         int32_t size;
@@ -252,6 +254,9 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
             size = c.i32();
             if (!c.ok || size < 0 || !c.need((size_t)size)) { err = "exr: truncated tile chunk"; return false; }
             if (lx != 0 || ly != 0 || tx < 0 || ty < 0 || (size_t)tx >= ntx || (size_t)ty >= nty) { err = "exr: tile outside the level-0 grid"; return false; }
+            // the offset table is indexed by tile coordinates: entry b must be tile b, so no two of the parallel
+            // workers ever write the same pixels
+            if ((size_t)ty * ntx + (size_t)tx != b) { err = "exr: tile chunk does not match its offset-table entry"; return false; }
             x0 = (long)tx * tile_w; y0 = (long)ty * tile_h;
             bw = std::min<long>(tile_w, W - x0); nl = std::min<long>(tile_h, H - y0);
         } else {
@@ -260,6 +265,9 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
             if (!c.ok || size < 0 || !c.need((size_t)size)) { err = "exr: truncated chunk"; return false; }
             y0 = (long)y - dw[1];
             if (y0 < 0 || y0 >= H) { err = "exr: chunk outside the data window"; return false; }
+            // entry b of the line-offset table is the block of rows [b*lines_per_block, ...): a chunk that starts
+            // elsewhere is corrupt, and accepting it would let two parallel workers write the same rows
+            if (y0 % lines_per_block != 0 || (size_t)(y0 / lines_per_block) != b) { err = "exr: chunk does not match its offset-table entry"; return false; }
             nl = std::min<long>(lines_per_block, H - y0);
         }
         const size_t line_bytes = px_bytes * (size_t)bw;

@@ -99,10 +99,18 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
     const auto wall0 = std::chrono::steady_clock::now();
     int next_upload = f_lo;
     auto upload = [&](int f) -> int {
-        if (f - f_lo >= ring) {   // the slot still holds frame f-ring, last read by output (f-ring)+k
+        if (f - f_lo >= ring) {   // the slot still holds frame f-ring, read by outputs (f-ring)-k .. (f-ring)+k
             int last_reader = f - ring + k;
             if (last_reader > first + count - 1) last_reader = first + count - 1;
-            if (last_reader >= first) MID_HIP(hipStreamWaitEvent(ctx->upload, c1.ev[(last_reader - first) / B], 0));
+            if (last_reader >= first) {
+                // Batches alternate between the two kernel streams, so the readers of this slot sit on BOTH:
+                // batch lb and every earlier same-parity batch are ordered before c1[lb] by stream order, the
+                // other-parity readers (lb-1, lb-3, ...) before c1[lb-1].  Waiting on both makes the overwrite
+                // safe by construction, not by the kernels happening to finish in launch order.
+                const int lb = (last_reader - first) / B;
+                MID_HIP(hipStreamWaitEvent(ctx->upload, c1.ev[lb], 0));
+                if (lb >= 1) MID_HIP(hipStreamWaitEvent(ctx->upload, c1.ev[lb - 1], 0));
+            }
         }
         MID_HIP(hipEventRecord(up0.ev[f - f_lo], ctx->upload));
         MID_HIP(hipMemcpyAsync(slot(f), host_frames[f], in_bytes, hipMemcpyHostToDevice, ctx->upload));
@@ -124,6 +132,9 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
         // lower or higher priority than the first: 2410-2430; splitting every download over two copy streams: 1860)
         hipStream_t cs = overlap && (bi & 1) ? ctx->compute2 : ctx->compute;
         MID_HIP(hipStreamWaitEvent(cs, up1.ev[need - f_lo], 0));
+        // Output slot bi % DEPTH was written by batch bi-DEPTH and is read only by download(bi-DEPTH), which
+        // itself waited for c1[bi-DEPTH]: d1[bi-DEPTH] therefore orders both the writer and the only reader of
+        // the slot before this batch, whichever kernel stream they ran on.
         if (bi >= DEPTH) MID_HIP(hipStreamWaitEvent(cs, d1.ev[bi - DEPTH], 0));
 
         const int lo = b0 - k < 0 ? 0 : b0 - k;

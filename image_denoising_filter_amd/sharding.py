@@ -84,6 +84,7 @@ def exchange_halo(local: Sequence[torch.Tensor], n_frames: int, k: int, group=No
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        _order_after_halo(local)
     return have
 
 
@@ -114,18 +115,55 @@ def start_halo_exchange(local: Sequence[torch.Tensor], n_frames: int, k: int, gr
     return have, (dist.batch_isend_irecv(ops) if ops else [])
 
 
-def temporal_block_overlapped(launch, local: Sequence[torch.Tensor], n_frames: int, k: int, group=None):
+def _order_after_halo(tensors):
+    """Stream rule for device backends.  With backend "nccl" (RCCL) `req.wait()` only makes the CURRENT torch
+    stream wait for the transfer; kernels launched through the C-ABI run on the stream handle they are given,
+    and the handle 0 (torch's default stream) means "the context's own stream" there -- a stream RCCL knows
+    nothing about.  So: callers launch on torch.cuda.current_stream().cuda_stream with a non-default stream
+    current (what bench.py does), and if the current stream IS the default one this helper falls back to a
+    host-side synchronize of it, which orders every later launch on any stream after the received halo."""
+    if tensors and getattr(tensors[0], "is_cuda", False):
+        cur = torch.cuda.current_stream(tensors[0].device)
+        if cur.cuda_stream == 0:
+            cur.synchronize()
+
+
+def launch_stream_for(tensor):
+    """The stream handle a C-ABI launch must use to be ordered after RCCL halo receives on `tensor`'s device:
+    the current torch stream.  Raises if that is the default stream (handle 0 = the library's own stream)."""
+    if not getattr(tensor, "is_cuda", False):
+        return None
+    h = torch.cuda.current_stream(tensor.device).cuda_stream
+    if h == 0:
+        raise RuntimeError("make a non-default torch stream current (torch.cuda.set_stream) before launching on "
+                           "halo frames: stream handle 0 means the library's own stream to the C-ABI, which is "
+                           "not ordered after RCCL's receives")
+    return h
+
+
+def temporal_block_overlapped(launch, local: Sequence[torch.Tensor], n_frames: int, k: int, group=None, hooks=None):
     """Temporal NLM of this rank's block with the halo exchange hidden behind the interior frames.
 
     `launch(frames, first, count, out_offset)` filters outputs [first, first+count) of the ordered
     frame list `frames` (what mid_nlm_temporal takes) and stores them at block-relative position
     out_offset.  Order of events: post the halo transfers -> launch the interior outputs (their
     windows lie inside the block, no halo needed) -> wait for the transfers -> launch the <= 2k
-    boundary outputs.  Returns the `have` dict (frames by global id)."""
+    boundary outputs.  Returns the `have` dict (frames by global id).
+
+    Streams (device backends): `launch` must enqueue on the current torch stream, see _order_after_halo.
+    hooks (optional dict): 'stats' -> dict that receives halo_bytes_recv / halo_bytes_sent / halo_frames_recv;
+    'before_wait' / 'after_wait' -> callables run around the wait for the transfers (bench.py records stream
+    events there to time how long the boundary frames were held up by the halo)."""
+    hooks = hooks or {}
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     start, count = partition(n_frames, world)[rank]
     have, reqs = start_halo_exchange(local, n_frames, k, group)
+    if "stats" in hooks:
+        recv, send = halo_plan(n_frames, world, k, rank) if (world > 1 and k > 0 and count > 0) else ([], [])
+        fb = local[0].numel() * local[0].element_size() if count else 0
+        hooks["stats"].update(halo_frames_recv=sum(len(i) for _, i in recv), halo_bytes_recv=fb * sum(len(i) for _, i in recv),
+                              halo_bytes_sent=fb * sum(len(i) for _, i in send))
     if count == 0:
         return have
     # outputs whose window t-k..t+k (clipped at the sequence ends) stays inside [start, start+count)
@@ -139,8 +177,14 @@ def temporal_block_overlapped(launch, local: Sequence[torch.Tensor], n_frames: i
             # restrict the table so that clipping at the block edge never replaces a missing halo frame
             w_lo, w_hi = max(start, lo_int - k), min(start + count - 1, hi_int - 1 + k)
             launch([have[f] for f in range(w_lo, w_hi + 1)], lo_int - w_lo, hi_int - lo_int, lo_int - start)
+    if "before_wait" in hooks:
+        hooks["before_wait"]()
     for r in reqs:
         r.wait()
+    if reqs:
+        _order_after_halo(local)
+    if "after_wait" in hooks:
+        hooks["after_wait"]()
     for a, b in ((start, min(lo_int, start + count)), (max(hi_int, lo_int), start + count)):
         if b > a:
             w_lo, w_hi = max(0, a - k), min(n_frames - 1, b - 1 + k)
@@ -157,10 +201,14 @@ def window_for_block(have, n_frames: int, k: int, start: int, count: int):
 
 def temporal_nlm_block(ctx, have, n_frames, k, start, count, outs, hparam, search, patch, fmt=0, stream=None):
     """Runs the temporal NLM of this rank's block on device tensors (torch CUDA tensors or anything
-    with data_ptr()); `outs` are `count` preallocated RGBA32F tensors."""
+    with data_ptr()); `outs` are `count` preallocated RGBA32F tensors.
+    stream=None means the CURRENT torch stream for CUDA tensors -- the one exchange_halo()'s waits ordered -- and
+    raises if that is the default stream (see launch_stream_for); pass an explicit handle to override."""
     if count == 0:
         return
     frames, first = window_for_block(have, n_frames, k, start, count)
+    if stream is None:
+        stream = launch_stream_for(frames[0])
     h, w = frames[0].shape[0], frames[0].shape[1]
     ctx.nlm_temporal_dev([f.data_ptr() for f in frames], [o.data_ptr() for o in outs], w, h, hparam,
                          search, patch, k, first, count, fmt, stream)

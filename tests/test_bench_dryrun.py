@@ -34,3 +34,35 @@ def test_bench_control_flow(n):
     assert len(lines) == 1, "exactly one JSON line, from rank 0"
     d = json.loads(lines[0])
     assert d["dry_run"] is True and d["n_gpus"] == n and d["value"] is None
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_spawns_its_own_ranks(n):
+    """`python bench.py --gpus N` with NO launcher and no RANK/WORLD_SIZE in the environment: the parent starts N
+    ranks itself (before anything touches a GPU), relays rank 0's one JSON line, and n_gpus is the process
+    group's world size."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--frames", "4", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == n
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A rank that dies makes the launcher stop the others and return non-zero -- never a 1-GPU number."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["MID_BENCH_TEST_FAIL_RANK"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "4", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_a_mismatched_launcher():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

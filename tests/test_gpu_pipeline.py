@@ -25,6 +25,21 @@ def test_sequence_matches_direct_call(ctx, k, n):
     assert max(rel_err(a, b) for a, b in zip(direct, ref)) < 2e-5
 
 
+@pytest.mark.parametrize("k,n", [(2, 24), (1, 19)])
+def test_ring_slots_are_recycled_safely(ctx, k, n):
+    """n >> ring (2k+4 slots): every slot is overwritten several times while outputs alternate between the two
+    kernel streams.  upload(f) waits for the slot's last reader on EACH stream (csrc/pipeline.cpp), so the result
+    equals the direct temporal call bit for bit -- also for a sub-range (a frame block with its halo)."""
+    rng = np.random.default_rng(900 + k)
+    h, w = 48, 90
+    frames = [(synth_hdr(rng, h, w) * 0.25).astype(np.float32) for _ in range(n)]
+    direct = ctx.nlm_temporal(frames, k=k)
+    outs, _ = ctx.sequence_nlm(frames, k=k, overlap=True)
+    assert all(np.array_equal(a, b) for a, b in zip(outs, direct))
+    part, _ = ctx.sequence_nlm(frames, k=k, overlap=True, first=5, count=n - 8)
+    assert all(np.array_equal(a, b) for a, b in zip(part, direct[5:n - 3]))
+
+
 def test_sequence_ldr_frames(ctx):
     from conftest import synth_ldr
     rng = np.random.default_rng(3)

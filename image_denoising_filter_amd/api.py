@@ -177,8 +177,8 @@ class Context:
         _check(lib.mid_bilateral(self.handle, ctypes.byref(p), in_ptr, out_ptr, stream), "mid_bilateral")
 
     def nlm_temporal_dev(self, frame_ptrs, out_ptrs, w, h, hparam, search, patch, k, first, count, fmt, stream=None):
-        if not (0 <= first and count >= 1 and first + count <= len(frame_ptrs)):
-            raise ValueError(f"outputs [{first}, {first + count}) are not inside the {len(frame_ptrs)} frames given")
+        # (the frame range itself is checked by the C side -> MID_ERR_INVALID; what C cannot see is the length of
+        # the ctypes output table it is about to read `count` entries of)
         if len(out_ptrs) < count:
             raise ValueError(f"{count} output frames asked for, only {len(out_ptrs)} output pointers given")
         p = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], fmt)

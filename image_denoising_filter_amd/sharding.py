@@ -166,17 +166,10 @@ def temporal_block_overlapped(launch, local: Sequence[torch.Tensor], n_frames: i
                               halo_bytes_sent=fb * sum(len(i) for _, i in send))
     if count == 0:
         return have
-    # outputs whose window t-k..t+k (clipped at the sequence ends) stays inside [start, start+count)
-    lo_int = start if start == 0 else start + k
-    hi_int = start + count if start + count == n_frames else start + count - k      # exclusive
-    if hi_int > lo_int:
-        own = [have[f] for f in range(start, start + count)]
-        if start == 0 and start + count == n_frames:
-            launch(own, 0, count, 0)
-        else:
-            # restrict the table so that clipping at the block edge never replaces a missing halo frame
-            w_lo, w_hi = max(start, lo_int - k), min(start + count - 1, hi_int - 1 + k)
-            launch([have[f] for f in range(w_lo, w_hi + 1)], lo_int - w_lo, hi_int - lo_int, lo_int - start)
+    plan = block_launch_plan(n_frames, world, k, rank)
+    for phase, w_lo, w_hi, first, cnt, off in plan:
+        if phase == "interior":
+            launch([have[f] for f in range(w_lo, w_hi + 1)], first, cnt, off)
     if "before_wait" in hooks:
         hooks["before_wait"]()
     for r in reqs:
@@ -185,11 +178,34 @@ def temporal_block_overlapped(launch, local: Sequence[torch.Tensor], n_frames: i
         _order_after_halo(local)
     if "after_wait" in hooks:
         hooks["after_wait"]()
+    for phase, w_lo, w_hi, first, cnt, off in plan:
+        if phase == "boundary":
+            launch([have[f] for f in range(w_lo, w_hi + 1)], first, cnt, off)
+    return have
+
+
+def block_launch_plan(n_frames: int, world: int, k: int, rank: int):
+    """The launches one rank makes for its block, as pure data: a list of
+    (phase, w_lo, w_hi, first, count, out_offset) where frames w_lo..w_hi (global ids) form the table handed to
+    mid_nlm_temporal, outputs are table entries [first, first+count), stored at block-relative out_offset.
+    phase "interior": every window t-k..t+k (clipped at the SEQUENCE ends only) lies inside the rank's own block,
+    so the launch needs no halo frame and can run while the halo is in flight; the table is restricted to the
+    block so that clipping at the block edge can never stand in for a missing halo frame.
+    phase "boundary": the <= 2k outputs next to a neighbouring block; their tables include the halo frames."""
+    start, count = partition(n_frames, world)[rank]
+    if count == 0:
+        return []
+    lo_int = start if start == 0 else start + k
+    hi_int = start + count if start + count == n_frames else start + count - k      # exclusive
+    plan = []
+    if hi_int > lo_int:
+        w_lo, w_hi = max(start, lo_int - k), min(start + count - 1, hi_int - 1 + k)
+        plan.append(("interior", w_lo, w_hi, lo_int - w_lo, hi_int - lo_int, lo_int - start))
     for a, b in ((start, min(lo_int, start + count)), (max(hi_int, lo_int), start + count)):
         if b > a:
             w_lo, w_hi = max(0, a - k), min(n_frames - 1, b - 1 + k)
-            launch([have[f] for f in range(w_lo, w_hi + 1)], a - w_lo, b - a, a - start)
-    return have
+            plan.append(("boundary", w_lo, w_hi, a - w_lo, b - a, a - start))
+    return plan
 
 
 def window_for_block(have, n_frames: int, k: int, start: int, count: int):

@@ -78,7 +78,7 @@ def _worker(rank, world, port, n, k, h, w, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,k", [(2, 6, 2), (2, 5, 1), (3, 4, 2), (2, 12, 2), (3, 13, 1)])
+@pytest.mark.parametrize("world,n,k", [(2, 6, 2), (2, 5, 1), (3, 4, 2), (2, 12, 2), (3, 13, 1), (8, 64, 2)])   # last = BASELINE configs[4]
 def test_sharded_sequence_equals_single_shard(world, n, k):
     import oracle
     h, w = 9, 12

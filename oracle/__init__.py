@@ -123,7 +123,7 @@ def cpu_bilateral(img, radius=10, sigma_s=10.0, sigma_c=0.2, blue_bug=True, thre
     return out
 
 
-def nlm_temporal(frames, k=0, hparam=0.5, search=(-7, 7), patch=(-3, 3), first=0, count=None):
+def nlm_temporal(frames, k=0, hparam=0.5, search=(-7, 7), patch=(-3, 3), first=0, count=None, threads=1):
     """The multi-frame mode as the product defines it: for output t accumulate over frames
     max(0,t-k)..min(n-1,t+k) in ascending order with target = frame t, then normalize."""
     n = len(frames)
@@ -133,7 +133,7 @@ def nlm_temporal(frames, k=0, hparam=0.5, search=(-7, 7), patch=(-3, 3), first=0
         h, w = frames[t].shape[:2]
         W = np.zeros((h, w, 8), np.float32)
         for f in range(max(0, t - k), min(n - 1, t + k) + 1):
-            W = nlm_accum(frames[t], frames[f], W, hparam, search, patch)
+            W = nlm_accum(frames[t], frames[f], W, hparam, search, patch, threads=threads)
         outs.append(normalize(W))
     return outs
 

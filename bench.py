@@ -467,6 +467,15 @@ def main():
 
         guarded("bilateral", extra_bilateral)
 
+        def extra_bilateral_batch():
+            # all F resident frames in ONE launch (mid_bilateral_batch): every round of workgroups is full
+            s = time_gpu(lambda: ctx.bilateral_batch_dev(fptr, optr, W, H, 8, 2.0, 0.2, mid.LAYOUT_LINEAR, mid.FMT_RGBA32F, stream), 5)
+            also["bilateral_r8_linear_batch"] = {"Mpixel/s": round(F * NPIX / 1e6 / s, 1), "ms_per_frame": round(s * 1e3 / F, 4), "frames": F,
+                                                 "valu_frac": round(BIL_FLOP_PER_PX * F * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                                 "hbm_GBs": round(BIL_BYTES_PER_PX * F * NPIX / s / 1e9, 1)}
+
+        guarded("bilateral_batch", extra_bilateral_batch)
+
         def extra_layers():
             # BASELINE configs[3]: 4 RGBA8 guide layers, fused layer-aware bilateral r=8 (16+4L+16 B/px)
             lay = [(f[..., :4].clamp(0, 1) * 255).to(torch.uint8).contiguous() for f in frames[:4]]

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "mid_memset": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_size_t, _P]),
     "mid_stream_sync": (ctypes.c_int, [_P, _P]),
     "mid_bilateral": (ctypes.c_int, [_P, ctypes.POINTER(BilateralParams), _P, _P, _P]),
+    "mid_bilateral_batch": (ctypes.c_int, [_P, ctypes.POINTER(BilateralParams), c_void_pp, c_void_pp, ctypes.c_int, _P]),
     "mid_bilateral_layers_accum": (ctypes.c_int, [_P, ctypes.POINTER(BilateralParams), _P, _P, _P, _P]),
     "mid_bilateral_layers": (ctypes.c_int, [_P, ctypes.POINTER(BilateralParams), _P, c_void_pp, ctypes.c_int, _P, _P]),
     "mid_nlm_accum": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), _P, _P, _P, _P]),
@@ -92,6 +93,8 @@ _SIGNATURES = {
                                           ctypes.POINTER(ctypes.c_float)]),
     "mid_image_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Image)]),
     "mid_image_free": (None, [ctypes.POINTER(Image)]),
+    "mid_image_load_pinned": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(Image)]),
+    "mid_image_free_pinned": (ctypes.c_int, [_P, ctypes.POINTER(Image)]),
     "mid_image_save": (ctypes.c_int, [ctypes.c_char_p, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "mid_timer_create": (ctypes.c_int, [_P, c_void_pp]),
     "mid_timer_destroy": (ctypes.c_int, [_P]),

@@ -176,6 +176,14 @@ class Context:
         p = BilateralParams(w, h, sigma_s, sigma_c, radius, layout, fmt)
         _check(lib.mid_bilateral(self.handle, ctypes.byref(p), in_ptr, out_ptr, stream), "mid_bilateral")
 
+    def bilateral_batch_dev(self, in_ptrs, out_ptrs, w, h, radius, sigma_s, sigma_c, layout, fmt, stream=None):
+        if len(out_ptrs) != len(in_ptrs) or not in_ptrs:
+            raise ValueError(f"{len(in_ptrs)} input and {len(out_ptrs)} output pointers")
+        p = BilateralParams(w, h, sigma_s, sigma_c, radius, layout, fmt)
+        fi = (ctypes.c_void_p * len(in_ptrs))(*in_ptrs)
+        fo = (ctypes.c_void_p * len(out_ptrs))(*out_ptrs)
+        _check(lib.mid_bilateral_batch(self.handle, ctypes.byref(p), fi, fo, len(in_ptrs), stream), "mid_bilateral_batch")
+
     def nlm_temporal_dev(self, frame_ptrs, out_ptrs, w, h, hparam, search, patch, k, first, count, fmt, stream=None):
         # (the frame range itself is checked by the C side -> MID_ERR_INVALID; what C cannot see is the length of
         # the ctypes output table it is about to read `count` entries of)
@@ -196,6 +204,16 @@ class Context:
         d_in, d_out = self.upload(img), self.alloc(w * h * 16)
         self.bilateral_dev(d_in.ptr, d_out.ptr, w, h, radius, sigma_s, sigma_c, lay, _fmt_of(img))
         return self.download(d_out, (h, w, 4), np.float32)
+
+    def bilateral_batch(self, frames, radius, sigma_s=2.0, sigma_c=0.2, layout="texture"):
+        """n independent frames, one launch (mid_bilateral_batch)."""
+        frames = _same_frames(frames, "bilateral_batch")
+        h, w = frames[0].shape[:2]
+        lay = {"texture": LAYOUT_TEXTURE, "linear": LAYOUT_LINEAR}[layout]
+        d_in = [self.upload(f) for f in frames]
+        d_out = [self.alloc(w * h * 16) for _ in frames]
+        self.bilateral_batch_dev([d.ptr for d in d_in], [d.ptr for d in d_out], w, h, radius, sigma_s, sigma_c, lay, _fmt_of(frames[0]))
+        return [self.download(d, (h, w, 4), np.float32) for d in d_out]
 
     def bilateral_layers_accum(self, img, layer, W, radius, sigma_s=2.0, sigma_c=0.2):
         """One dispatch of bialteral_layers.comp: returns W + this layer's sums."""

@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace mid {
 
@@ -31,6 +32,11 @@ struct BilArgs {
     const uint32_t *layers[16];
 };
 
+// Frame tables of the batched plain bilateral (mid_bilateral_batch): passed by value in kernarg space like the NLM
+// kernels' tables.  Single-frame launches pass the empty BilOne instead, so their kernarg block stays small.
+struct BilBatch { FrameTable in; OutTable out; };
+struct BilOne {};
+
 __device__ __forceinline__ unsigned xcd_remap_b(unsigned bid, unsigned nwg)
 {
     const unsigned q = nwg >> 3, r = nwg & 7u, x = bid & 7u, i = bid >> 3;
@@ -40,9 +46,10 @@ __device__ __forceinline__ unsigned xcd_remap_b(unsigned bid, unsigned nwg)
 // MODE 0: plain bilateral (range weight and colour from `in`)
 // MODE 1: layers, accumulate one layer into W      (one dispatch of bialteral_layers.comp)
 // MODE 2: layers, all layers fused + normalize     (loop src/main.cpp:1610-1623 + normalize.comp)
-template <int R, int P, int NW, int FMT, bool LINEAR, int MODE, int SB = 8>
-__global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
+template <int R, int P, int NW, int FMT, bool LINEAR, int MODE, typename BT, int SB = 8>
+__global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, const BT bt)
 {
+    constexpr bool BATCH = std::is_same<BT, BilBatch>::value;
     constexpr int TILE_W = 64, TILE_H = NW * P;
     constexpr int LW = TILE_W + 2 * R, LH = TILE_H + 2 * R;
     constexpr int MR = P + 2 * R;   // tile rows a lane walks per column offset
@@ -52,7 +59,19 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
     float4 *gde_t = (MODE == 0) ? lds : lds + LW * LH;    // range-weight source (guide)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const unsigned flat = xcd_remap_b(blockIdx.x, gridDim.x);
+    unsigned flat;
+    const void *in = a.in;
+    float4 *out = a.out;
+    if constexpr (BATCH) {
+        // frames in launch order, tiles remapped inside their frame (every XCD gets a contiguous run of each frame)
+        const unsigned tiles = (unsigned)(a.tiles_x * a.tiles_y);
+        const unsigned fz = blockIdx.x / tiles;
+        flat = xcd_remap_in_frame(blockIdx.x - fz * tiles, tiles, fz);
+        in = bt.in.p[fz];
+        out = (float4 *)bt.out.p[fz];
+    } else {
+        flat = xcd_remap_b(blockIdx.x, gridDim.x);
+    }
     const int ty = (int)(flat / (unsigned)a.tiles_x), tx = (int)(flat - (unsigned)ty * a.tiles_x);
     const int w = a.w, h = a.h;
     const int X0 = tx * TILE_W, Y0 = ty * TILE_H;
@@ -61,7 +80,7 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
 
     // The guide colours (the image itself in MODE 0) are pre-multiplied by sqrt(-kc), so -|dc|^2 is already the
     // colour part of the exp2 argument and the FMA chain can start from the spatial term: 12 ops per tap, not 13.
-    fill_tile<FMT, LINEAR>(img_t, LW, LH, a.in, w, h, X0 - R, Y0 - R, tid, NW * 64, MODE == 0 ? a.sc : 1.0f);
+    fill_tile<FMT, LINEAR>(img_t, LW, LH, in, w, h, X0 - R, Y0 - R, tid, NW * 64, MODE == 0 ? a.sc : 1.0f);
 
     // spatial exponent by |j|: ks * j^2 (wave-uniform)
     float sj[R + 1];
@@ -138,12 +157,12 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
         if (gy >= h) break;
         const size_t idx = (size_t)gy * w + gx;
         if (MODE == 0) {
-            a.out[idx] = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
+            out[idx] = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
         } else if (MODE == 2) {
             float4 o;
             if (totw[k] == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);
             else o = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
-            a.out[idx] = o;
+            out[idx] = o;
         } else {
             float4 *wp = (float4 *)(a.W + idx);
             float4 wc = wp[0], nw = wp[1];
@@ -156,23 +175,35 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a)
 
 // Any radius without a tuned instantiation: the same LDS-tiled scheme with the radius as a run-time
 // value (loops not unrolled, spatial exponent computed per tap row).  8 waves x 2 rows per workgroup.
-template <int FMT, bool LINEAR, int MODE>
-__global__ __launch_bounds__(512) void bilateral_rt_kernel(const BilArgs a, const int R)
+template <int FMT, bool LINEAR, int MODE, typename BT>
+__global__ __launch_bounds__(512) void bilateral_rt_kernel(const BilArgs a, const int R, const BT bt)
 {
+    constexpr bool BATCH = std::is_same<BT, BilBatch>::value;
     constexpr int NW = 8, P = 2, TILE_W = 64, TILE_H = NW * P;
     const int LW = TILE_W + 2 * R, LH = TILE_H + 2 * R;
     extern __shared__ float4 lds[];
     float4 *img_t = lds;
     float4 *gde_t = (MODE == 0) ? lds : lds + LW * LH;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const unsigned flat = xcd_remap_b(blockIdx.x, gridDim.x);
+    unsigned flat;
+    const void *in = a.in;
+    float4 *out = a.out;
+    if constexpr (BATCH) {
+        const unsigned tiles = (unsigned)(a.tiles_x * a.tiles_y);
+        const unsigned fz = blockIdx.x / tiles;
+        flat = xcd_remap_in_frame(blockIdx.x - fz * tiles, tiles, fz);
+        in = bt.in.p[fz];
+        out = (float4 *)bt.out.p[fz];
+    } else {
+        flat = xcd_remap_b(blockIdx.x, gridDim.x);
+    }
     const int ty = (int)(flat / (unsigned)a.tiles_x), tx = (int)(flat - (unsigned)ty * a.tiles_x);
     const int w = a.w, h = a.h;
     const int X0 = tx * TILE_W, Y0 = ty * TILE_H;
     const int gx = X0 + lane, yb = Y0 + wv * P;
     const bool wave_active = yb < h;
 
-    fill_tile<FMT, LINEAR>(img_t, LW, LH, a.in, w, h, X0 - R, Y0 - R, tid, NW * 64, MODE == 0 ? a.sc : 1.0f);
+    fill_tile<FMT, LINEAR>(img_t, LW, LH, in, w, h, X0 - R, Y0 - R, tid, NW * 64, MODE == 0 ? a.sc : 1.0f);
     float4 tot[P];
     float totw[P];
 #pragma unroll
@@ -237,7 +268,7 @@ __global__ __launch_bounds__(512) void bilateral_rt_kernel(const BilArgs a, cons
             float4 o;
             if (MODE == 2 && totw[k] == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);
             else o = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
-            a.out[idx] = o;
+            out[idx] = o;
         }
     }
 }
@@ -292,47 +323,51 @@ __global__ __launch_bounds__(256) void bilateral_generic_kernel(const BilArgs a,
     }
 }
 
-template <int R, int P, int NW, int FMT, bool LINEAR, int MODE, int SB = 8>
-static int launch_tiled(mid_ctx *ctx, BilArgs &a, hipStream_t s)
+template <int R, int P, int NW, int FMT, bool LINEAR, int MODE, typename BT, int SB = 8>
+static int launch_tiled(mid_ctx *ctx, BilArgs &a, const BT &bt, int n_frames, hipStream_t s)
 {
     constexpr int LW = 64 + 2 * R, LH = NW * P + 2 * R;
     constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float4) * (MODE == 0 ? 1 : 2);
-    auto kern = bilateral_kernel<R, P, NW, FMT, LINEAR, MODE, SB>;
+    auto kern = bilateral_kernel<R, P, NW, FMT, LINEAR, MODE, BT, SB>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "bilateral tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     if (int rc = ensure_lds(ctx, (const void *)kern, lds_bytes)) return rc;
     a.tiles_x = (int)cdiv(a.w, 64);
     a.tiles_y = (int)cdiv(a.h, NW * P);
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles_x * a.tiles_y), dim3(NW * 64), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles_x * a.tiles_y * (unsigned)n_frames), dim3(NW * 64), lds_bytes, s, a, bt);
     MID_HIP(hipGetLastError());
     return MID_OK;
 }
 
-template <int FMT, bool LINEAR, int MODE>
-static int dispatch_radius(mid_ctx *ctx, int radius, BilArgs &a, hipStream_t s)
+// n_frames > 1 only with BT = BilBatch (plain bilateral, MODE 0): grid = tiles x frames.
+template <int FMT, bool LINEAR, int MODE, typename BT = BilOne>
+static int dispatch_radius(mid_ctx *ctx, int radius, BilArgs &a, hipStream_t s, const BT &bt = BT{}, int n_frames = 1)
 {
     // Tile shapes by A/B on MI355X (tools/ab_bil.py): the kernel is latency-sensitive, so many
     // independent waves (P = 2 rows per lane, 8 waves per workgroup) beat deeper register blocking.
     switch (radius) {
-    case 4:  return launch_tiled<4, 2, 8, FMT, LINEAR, MODE>(ctx, a, s);    // BASELINE config 1 window
-    case 8:  return launch_tiled<8, 2, 8, FMT, LINEAR, MODE>(ctx, a, s);    // BASELINE configs 2 and 4
-    case 10: return launch_tiled<10, 2, 16, FMT, LINEAR, MODE>(ctx, a, s);  // CPU path window, src/main.cpp:1819
+    case 4:  return launch_tiled<4, 2, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);    // BASELINE config 1 window
+    case 8:  return launch_tiled<8, 2, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);    // BASELINE configs 2 and 4
+    case 10: return launch_tiled<10, 2, 16, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);  // CPU path window, src/main.cpp:1819
     case 20:                                                                 // TEXEL_WINDOW as shipped
-        return launch_tiled<20, 1, 8, FMT, LINEAR, MODE>(ctx, a, s);          // 80 KB tile: two workgroups per CU (or image + guide tile)
+        return launch_tiled<20, 1, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);          // 80 KB tile: two workgroups per CU (or image + guide tile)
     default: break;
     }
     {   // run-time radius, LDS tiled
         const size_t lds_bytes = (size_t)(64 + 2 * radius) * (16 + 2 * radius) * sizeof(float4) * (MODE == 0 ? 1 : 2);
         if ((int)lds_bytes <= ctx->lds_max) {
-            auto kern = bilateral_rt_kernel<FMT, LINEAR, MODE>;
+            auto kern = bilateral_rt_kernel<FMT, LINEAR, MODE, BT>;
             if (int rc = ensure_lds(ctx, (const void *)kern, (size_t)ctx->lds_max)) return rc;
             a.tiles_x = (int)cdiv(a.w, 64);
             a.tiles_y = (int)cdiv(a.h, 16);
-            hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles_x * a.tiles_y), dim3(512), lds_bytes, s, a, radius);
+            hipLaunchKernelGGL(kern, dim3((unsigned)a.tiles_x * a.tiles_y * (unsigned)n_frames), dim3(512), lds_bytes, s, a, radius, bt);
             MID_HIP(hipGetLastError());
             return MID_OK;
         }
     }
+    // (unreachable for the plain bilateral: its single tile fits LDS for every legal radius; only the two-tile
+    // layer modes at r > 16 get here, and those are never batched)
+    if (n_frames != 1) return set_error(MID_ERR_UNSUPPORTED, "bilateral: no batched kernel for radius %d", radius);
     dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16));
     hipLaunchKernelGGL((bilateral_generic_kernel<FMT, LINEAR, MODE>), grid, dim3(256), 0, s, a, radius);
     MID_HIP(hipGetLastError());
@@ -416,4 +451,33 @@ extern "C" int mid_bilateral_layers(mid_ctx *ctx, const mid_bilateral_params *p,
     }
     return p->format == MID_FMT_RGBA8 ? dispatch_radius<MID_FMT_RGBA8, false, 2>(ctx, p->radius, a, b.s)
                                       : dispatch_radius<MID_FMT_RGBA32F, false, 2>(ctx, p->radius, a, b.s);
+}
+
+extern "C" int mid_bilateral_batch(mid_ctx *ctx, const mid_bilateral_params *p, const void *const *in,
+                                   mid_pixel *const *out, int n_frames, void *stream)
+{
+    Bind b(ctx, stream);
+    if (b.rc) return b.rc;
+    if (int rc = check_params(p, "bilateral_batch")) return rc;
+    MID_REQUIRE(in && out, "bilateral_batch: NULL table");
+    MID_REQUIRE(n_frames >= 1, "bilateral_batch: n_frames %d < 1", n_frames);
+    for (int i = 0; i < n_frames; ++i) {
+        MID_REQUIRE(in[i] && out[i], "bilateral_batch: frame %d is NULL", i);
+        MID_REQUIRE((const void *)in[i] != (const void *)out[i], "bilateral_batch: in-place filtering is not supported (frame %d)", i);
+    }
+    const bool lin = p->layout == MID_LAYOUT_LINEAR, u8 = p->format == MID_FMT_RGBA8;
+    for (int c0 = 0; c0 < n_frames; c0 += kMaxFrames) {          // one launch per kMaxFrames frames
+        const int cn = n_frames - c0 < kMaxFrames ? n_frames - c0 : kMaxFrames;
+        BilArgs a{};
+        fill_scales(p, a);
+        BilBatch bt{};
+        for (int i = 0; i < cn; ++i) { bt.in.p[i] = in[c0 + i]; bt.out.p[i] = out[c0 + i]; }
+        int rc;
+        if (lin) rc = u8 ? dispatch_radius<MID_FMT_RGBA8, true, 0, BilBatch>(ctx, p->radius, a, b.s, bt, cn)
+                         : dispatch_radius<MID_FMT_RGBA32F, true, 0, BilBatch>(ctx, p->radius, a, b.s, bt, cn);
+        else rc = u8 ? dispatch_radius<MID_FMT_RGBA8, false, 0, BilBatch>(ctx, p->radius, a, b.s, bt, cn)
+                     : dispatch_radius<MID_FMT_RGBA32F, false, 0, BilBatch>(ctx, p->radius, a, b.s, bt, cn);
+        if (rc) return rc;
+    }
+    return MID_OK;
 }

@@ -283,24 +283,46 @@ public:
         if (frameNames.empty()) throw std::runtime_error("no frames next to " + opt.image);
         const int n = (int)frameNames.size(), k = opt.temporal_k < 0 ? 2 : opt.temporal_k;
         std::cout << "\tloading " << n << " frames\n";
-        std::vector<HostImage> frames;
+        // Frames are decoded STRAIGHT INTO pinned host memory (mid_image_load_pinned) and the results land in pinned
+        // buffers too, so every copy of the pipeline is a true asynchronous DMA -- the reference memcpy's its decoded
+        // pixels into mapped staging memory the same way (LoadImageDataToBuffer, src/main.cpp:1105-1142).  Measured,
+        // 16 x 1080p RGBA32F through the pipeline: pinned 12.8 ms, pageable vectors 20.2 ms, vectors registered in
+        // place 25.1 ms.  Page-locking is per process, so the one context used for loading serves every device.
+        mid_ctx *io = nullptr;
+        MID_CHECK(mid_ctx_create(opt.device, &io));
+        struct Pinned {                                   // owns the pinned frames and outputs; released before `io`
+            mid_ctx *c;
+            std::vector<mid_image> frames;
+            std::vector<void *> outs;
+            ~Pinned()
+            {
+                for (auto &f : frames) (void)mid_image_free_pinned(c, &f);
+                for (auto o : outs) (void)mid_free_host(c, o);
+                mid_ctx_destroy(c);
+            }
+        } pin{io, {}, {}};
+        const auto tl0 = std::chrono::steady_clock::now();
         for (auto &f : frameNames) {
-            frames.push_back(load(f, false));
-            if (frames.back().w != frames[0].w || frames.back().h != frames[0].h || frames.back().format != frames[0].format)
+            mid_image img{};
+            if (mid_image_load_pinned(io, f.c_str(), &img)) throw std::runtime_error(mid_last_error());
+            pin.frames.push_back(img);
+            if (img.width != pin.frames[0].width || img.height != pin.frames[0].height || img.format != pin.frames[0].format)
                 throw std::runtime_error(f + ": size/format differs from the first frame");
         }
-        const int w = frames[0].w, h = frames[0].h, fmt = frames[0].format;
-        std::vector<const void *> in(n);
+        const double load_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
+        const int w = pin.frames[0].width, h = pin.frames[0].height, fmt = pin.frames[0].format;
         // LDR frames come back as RGBA8: the read-back conversion of GetImageFromGPU (:97-103) runs on the device
         // (mid_sequence_nlm_range_u8), a quarter of the download
         const bool hdr = fmt == MID_FMT_RGBA32F;
-        std::vector<std::vector<Pixel>> out(hdr ? n : 0, std::vector<Pixel>((size_t)w * h));
-        std::vector<std::vector<unsigned char>> out8(hdr ? 0 : n, std::vector<unsigned char>((size_t)w * h * 4));
-        for (int i = 0; i < n; ++i) in[i] = frames[i].bytes.data();
+        const size_t out_bytes = (size_t)w * h * (hdr ? 16 : 4);
+        std::vector<const void *> in(n);
+        for (int i = 0; i < n; ++i) {
+            in[i] = pin.frames[i].data;
+            void *o = nullptr;
+            MID_CHECK(mid_alloc_host(io, out_bytes, &o));
+            pin.outs.push_back(o);
+        }
         const int G = std::max(1, std::min(opt.gpus, n));
-        // Frames stay in pageable memory: HIP stages such copies itself, and that measured faster than pinning the
-        // vectors in place (20.2 vs 25.1 ms per 16 x 1080p RGBA32F; buffers from mid_alloc_host reach 12.8 ms but would
-        // need the decoders to write into them).
         std::vector<std::string> errors(G);
         std::vector<float> kern(G, 0.f), copy(G, 0.f);
         std::vector<std::thread> workers;
@@ -317,11 +339,11 @@ public:
                     float t[3] = {0, 0, 0};
                     if (hdr) {
                         std::vector<mid_pixel *> o(count);
-                        for (int i = 0; i < count; ++i) o[i] = (mid_pixel *)out[start + i].data();
+                        for (int i = 0; i < count; ++i) o[i] = (mid_pixel *)pin.outs[start + i];
                         MID_CHECK(mid_sequence_nlm_range(ctx, &p, in.data(), n, k, start, count, o.data(), 1, t));
                     } else {
                         std::vector<uint8_t *> o(count);
-                        for (int i = 0; i < count; ++i) o[i] = out8[start + i].data();
+                        for (int i = 0; i < count; ++i) o[i] = (uint8_t *)pin.outs[start + i];
                         MID_CHECK(mid_sequence_nlm_range_u8(ctx, &p, in.data(), n, k, start, count, o.data(), 1, t));
                     }
                     kern[g] = t[1]; copy[g] = t[2];
@@ -332,15 +354,14 @@ public:
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         m_execMs = *std::max_element(kern.begin(), kern.end());
         m_transferMs = *std::max_element(copy.begin(), copy.end());
+        std::cout << "\tdecoded " << n << " frames into pinned memory in " << load_sec << " sec\n";
         std::cout << "\t" << n << " frames, k=" << k << ", " << G << " device(s): " << sec << " sec, "
-                  << (double)n * w * h / 1e6 / sec << " Mpixel/s end to end\n";
+                  << (double)n * w * h / 1e6 / sec << " Mpixel/s end to end (host frames in -> host frames out)\n";
         for (int i = 0; i < n; ++i) {
-            const std::string name = "output-animation-" + fs::path(frameNames[i]).stem().string();
-            if (hdr) save(name, out[i], w, h, true);
-            else {
-                std::cout << "\t\tencoding png\n";
-                MID_CHECK(mid_image_save(out_path(name + ".png").c_str(), out8[i].data(), w, h, MID_FMT_RGBA8));   // lodepng::encode :1717
-            }
+            const std::string name = "output-animation-" + fs::path(frameNames[i]).stem().string() + (hdr ? ".exr" : ".png");
+            if (!hdr) std::cout << "\t\tencoding png\n";
+            // SaveEXR :1699 / lodepng::encode :1717, straight from the pinned result
+            MID_CHECK(mid_image_save(out_path(name).c_str(), pin.outs[i], w, h, hdr ? MID_FMT_RGBA32F : MID_FMT_RGBA8));
         }
     }
 

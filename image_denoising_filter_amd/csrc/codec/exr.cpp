@@ -148,6 +148,11 @@ static bool pxr24_decode(const uint8_t *in, size_t n_in, long bw, long nl, const
 
 bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<float> &rgba, std::string &err)
 {
+    return exr_decode_to(file, w, h, [&](size_t n) { rgba.assign(n, 0.f); return rgba.data(); }, err);
+}
+
+bool exr_decode_to(const std::vector<uint8_t> &file, int &w, int &h, const FloatAlloc &alloc, std::string &err)
+{
     Reader r{file.data(), file.data() + file.size()};
     if (file.size() < 8 || r.i32() != 20000630) { err = "exr: not an OpenEXR file"; return false; }
     const int32_t ver = r.i32();
@@ -236,8 +241,9 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
     for (auto &o : offsets) o = r.u64();
     if (!r.ok) { err = "exr: truncated offset table"; return false; }
 
-    rgba.assign((size_t)W * H * 4, 0.f);
-    for (size_t i = 0; i < (size_t)W * H; ++i) rgba[i * 4 + 3] = 1.0f;     // missing alpha = 1
+    float *const rgba = alloc((size_t)W * H * 4);
+    if (!rgba) { err = "exr: out of memory"; return false; }
+    for (size_t i = 0; i < (size_t)W * H; ++i) { rgba[i * 4] = rgba[i * 4 + 1] = rgba[i * 4 + 2] = 0.f; rgba[i * 4 + 3] = 1.0f; }   // missing alpha = 1
     std::vector<std::string> errs(nblocks);
     parallel_for(nblocks, [&](size_t b) {
         std::string &err = errs[b];
@@ -296,7 +302,7 @@ bool exr_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<fl
         }
         for (long l = 0; l < nl; ++l) {
             const uint8_t *line = data + (size_t)l * line_bytes;
-            float *out = rgba.data() + ((size_t)(y0 + l) * W + (size_t)x0) * 4;
+            float *out = rgba + ((size_t)(y0 + l) * W + (size_t)x0) * 4;
             auto read_ch = [&](int ch, int dst_lo, int dst_hi) {
                 const uint8_t *q = line + chpre[ch] * (size_t)bw;
                 for (long x = 0; x < bw; ++x) {

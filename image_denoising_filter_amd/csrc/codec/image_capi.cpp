@@ -16,7 +16,10 @@ static bool has_ext(const std::string &p, const char *ext)
     return true;
 }
 
-extern "C" int mid_image_load(const char *path, mid_image *out)
+// Shared body of mid_image_load / mid_image_load_pinned: `get(bytes)` provides the pixel memory (called once, after
+// the header checks), `drop(ptr)` takes it back when decoding fails afterwards.
+template <class Get, class Drop>
+static int load_impl(const char *path, mid_image *out, Get get, Drop drop)
 {
     MID_REQUIRE(path && out, "image_load: NULL argument");
     out->width = out->height = 0; out->format = 0; out->data = nullptr;
@@ -24,26 +27,48 @@ extern "C" int mid_image_load(const char *path, mid_image *out)
     std::string err;
     if (!codec::read_file(path, file, err)) return set_error(MID_ERR_IO, "%s", err.c_str());
     int w = 0, h = 0;
+    void *mem = nullptr;
+    bool ok = false;
     try {   // a corrupt header can ask for an absurd allocation: no exception may cross the C ABI
-    if (has_ext(path, ".exr")) {                      // m_isHDR = extension == ".exr", src/main.cpp:1380
-        std::vector<float> px;
-        if (!codec::exr_decode(file, w, h, px, err)) return set_error(MID_ERR_IO, "%s: %s", path, err.c_str());
-        out->data = malloc(px.size() * sizeof(float));
-        if (!out->data) return set_error(MID_ERR_IO, "out of host memory");
-        memcpy(out->data, px.data(), px.size() * sizeof(float));
-        out->format = MID_FMT_RGBA32F;
-    } else {
-        std::vector<uint8_t> px;
-        if (!codec::png_decode(file, w, h, px, err)) return set_error(MID_ERR_IO, "%s: %s", path, err.c_str());
-        out->data = malloc(px.size());
-        if (!out->data) return set_error(MID_ERR_IO, "out of host memory");
-        memcpy(out->data, px.data(), px.size());
-        out->format = MID_FMT_RGBA8;
-    }
+        if (has_ext(path, ".exr")) {                      // m_isHDR = extension == ".exr", src/main.cpp:1380
+            ok = codec::exr_decode_to(file, w, h, [&](size_t n) { mem = get(n * sizeof(float)); return (float *)mem; }, err);
+            out->format = MID_FMT_RGBA32F;
+        } else {
+            ok = codec::png_decode_to(file, w, h, [&](size_t n) { mem = get(n); return (uint8_t *)mem; }, err);
+            out->format = MID_FMT_RGBA8;
+        }
     } catch (const std::exception &e) {
-        return set_error(MID_ERR_IO, "%s: %s", path, e.what());
+        err = e.what();
+        ok = false;
     }
+    if (!ok) {
+        if (mem) drop(mem);
+        return set_error(MID_ERR_IO, "%s: %s", path, err.c_str());
+    }
+    out->data = mem;
     out->width = w; out->height = h;
+    return MID_OK;
+}
+
+extern "C" int mid_image_load(const char *path, mid_image *out)
+{
+    return load_impl(path, out, [](size_t bytes) { return malloc(bytes ? bytes : 1); }, [](void *p) { free(p); });
+}
+
+extern "C" int mid_image_load_pinned(mid_ctx *ctx, const char *path, mid_image *out)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    return load_impl(path, out,
+                     [](size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr; },
+                     [](void *p) { (void)hipHostFree(p); });
+}
+
+extern "C" int mid_image_free_pinned(mid_ctx *ctx, mid_image *img)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    if (img && img->data) { MID_HIP(hipHostFree(img->data)); img->data = nullptr; }
     return MID_OK;
 }
 

@@ -26,6 +26,15 @@ inline void parallel_for(size_t n, const std::function<void(size_t)> &fn)
     for (auto &t : th) t.join();
 }
 
+// The decoders write straight into memory the caller provides: `alloc(n)` is called exactly once, after the header
+// has been validated, and must return room for n elements (or nullptr = out of memory).  That is how frames are
+// decoded directly into pinned staging memory (mid_image_load_pinned), like the reference memcpy's decoded pixels
+// straight into its mapped staging buffer (src/main.cpp:1105-1142), with no intermediate copy.
+using ByteAlloc = std::function<uint8_t *(size_t)>;
+using FloatAlloc = std::function<float *(size_t)>;
+bool png_decode_to(const std::vector<uint8_t> &file, int &w, int &h, const ByteAlloc &alloc, std::string &err);
+bool exr_decode_to(const std::vector<uint8_t> &file, int &w, int &h, const FloatAlloc &alloc, std::string &err);
+
 bool png_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<uint8_t> &rgba, std::string &err);
 bool png_encode(const uint8_t *rgba, int w, int h, std::vector<uint8_t> &file, std::string &err);
 

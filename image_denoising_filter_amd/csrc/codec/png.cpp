@@ -113,6 +113,11 @@ static void to_rgba(const PngInfo &pi, const uint8_t *rows, size_t rowbytes, uin
 
 bool png_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<uint8_t> &rgba, std::string &err)
 {
+    return png_decode_to(file, w, h, [&](size_t n) { rgba.assign(n, 0); return rgba.data(); }, err);
+}
+
+bool png_decode_to(const std::vector<uint8_t> &file, int &w, int &h, const ByteAlloc &alloc, std::string &err)
+{
     static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (file.size() < 8 + 25 || memcmp(file.data(), sig, 8) != 0) { err = "png: not a PNG file"; return false; }
     PngInfo pi;
@@ -164,13 +169,15 @@ bool png_decode(const std::vector<uint8_t> &file, int &w, int &h, std::vector<ui
     const int zrc = uncompress(raw.data(), &got, idat.data(), (uLong)idat.size());
     if (zrc != Z_OK || got != raw_size) { err = "png: zlib stream is corrupt or has the wrong size"; return false; }
 
-    rgba.assign((size_t)pi.w * pi.h * 4, 0);
+    uint8_t *const rgba = alloc((size_t)pi.w * pi.h * 4);
+    if (!rgba) { err = "png: out of memory"; return false; }
+    memset(rgba, 0, (size_t)pi.w * pi.h * 4);
     const size_t bpp = bits >= 8 ? bits / 8 : 1;
     size_t off = 0;
     std::vector<uint8_t> rows;
     for (auto &s : subs) {
         if (!unfilter(raw.data() + off, s.rowbytes, s.h, bpp, rows, err)) return false;
-        to_rgba(pi, rows.data(), s.rowbytes, s.w, s.h, s.x0, s.y0, s.dx, s.dy, rgba.data());
+        to_rgba(pi, rows.data(), s.rowbytes, s.w, s.h, s.x0, s.y0, s.dx, s.dy, rgba);
         off += (s.rowbytes + 1) * s.h;
     }
     w = (int)pi.w; h = (int)pi.h;

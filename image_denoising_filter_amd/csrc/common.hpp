@@ -151,6 +151,25 @@ __device__ __forceinline__ void fill_tile(float4 *lds, int tw, int th, const voi
     }
 }
 
+// XCD-aware remap of a workgroup's tile index INSIDE its frame.  Workgroups are dealt round-robin over
+// the 8 XCDs (XCD = linear id % 8).  Frames stay in launch order -- every XCD gets an equal share of every
+// output frame, which matters because frames at the ends of a sequence have shorter temporal windows
+// (an earlier whole-grid remap gave XCD 0 only 3-neighbour frames and XCD 3 only 5-neighbour ones: 18 %
+// slower) -- and within a frame the tiles an XCD receives are made one contiguous run, so neighbouring
+// tiles share halo texels in that XCD's L2.  Bijective for any tile count; speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_remap_in_frame(unsigned t, unsigned tiles, unsigned frame)
+{
+    const unsigned off = (frame * tiles) & 7u;          // XCD of this frame's tile 0
+    const unsigned c = (t + off) & 7u;                  // XCD this workgroup runs on
+    unsigned start = 0;                                 // tiles owned by XCDs before c
+    for (unsigned cc = 0; cc < c; ++cc) {
+        const unsigned first = (cc + 8u - off) & 7u;
+        start += first < tiles ? (tiles - first + 7u) >> 3 : 0u;
+    }
+    const unsigned first_c = (c + 8u - off) & 7u;
+    return start + ((t - first_c) >> 3);
+}
+
 // Whole-wave lane shifts through DPP (no LDS traffic): value of lane l-1 / l+1; lanes without
 // a source read 0.
 __device__ __forceinline__ float wave_shr1(float v)   // result[l] = v[l-1]

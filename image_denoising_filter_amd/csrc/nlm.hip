@@ -84,25 +84,6 @@ __device__ __forceinline__ float horizontal_box(float v)
     return c;
 }
 
-// XCD-aware remap of a workgroup's tile index INSIDE its frame.  Workgroups are dealt round-robin over
-// the 8 XCDs (XCD = linear id % 8).  Frames stay in launch order -- every XCD gets an equal share of every
-// output frame, which matters because frames at the ends of a sequence have shorter temporal windows
-// (an earlier whole-grid remap gave XCD 0 only 3-neighbour frames and XCD 3 only 5-neighbour ones: 18 %
-// slower) -- and within a frame the tiles an XCD receives are made one contiguous run, so neighbouring
-// tiles share halo texels in that XCD's L2.  Bijective for any tile count; speed only, never correctness.
-__device__ __forceinline__ unsigned xcd_remap_in_frame(unsigned t, unsigned tiles, unsigned frame)
-{
-    const unsigned off = (frame * tiles) & 7u;          // XCD of this frame's tile 0
-    const unsigned c = (t + off) & 7u;                  // XCD this workgroup runs on
-    unsigned start = 0;                                 // tiles owned by XCDs before c
-    for (unsigned cc = 0; cc < c; ++cc) {
-        const unsigned first = (cc + 8u - off) & 7u;
-        start += first < tiles ? (tiles - first + 7u) >> 3 : 0u;
-    }
-    const unsigned first_c = (c + 8u - off) & 7u;
-    return start + ((t - first_c) >> 3);
-}
-
 template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1>
 __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 {

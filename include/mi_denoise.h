@@ -124,6 +124,12 @@ int mid_stream_sync(mid_ctx *ctx, void *stream);                     /* vkWaitFo
  * {0: vec4 out[N]; 1: image}. */
 int mid_bilateral(mid_ctx *ctx, const mid_bilateral_params *p,
                   const void *in, mid_pixel *out, void *stream);
+/* The same dispatch for n_frames independent frames of one size in ONE launch (grid = tiles x frames): what the
+ * reference does by calling RunOnGPU once per file (src/main.cpp:1952-1985), without the per-launch tail -- a 1080p
+ * frame is 2.66 rounds of workgroups, a batch fills every round.  in/out: host arrays of n_frames device pointers.
+ * Results are bit-identical to n_frames calls of mid_bilateral (same tile code). */
+int mid_bilateral_batch(mid_ctx *ctx, const mid_bilateral_params *p, const void *const *in /* n_frames device ptrs */,
+                        mid_pixel *const *out /* n_frames device ptrs */, int n_frames, void *stream);
 
 /* ---- a3: layer-guided bilateral ---------------------------------------------------------
  * mid_bilateral_layers_accum = one dispatch of shaders/bialteral_layers.comp
@@ -213,6 +219,12 @@ typedef struct mid_image {
 } mid_image;
 int  mid_image_load(const char *path, mid_image *out);
 void mid_image_free(mid_image *img);
+/* The same decode, but the pixels are written DIRECTLY into pinned (page-locked) host memory of `ctx`'s device, so the
+ * frame can be handed to mid_sequence_nlm* / mid_memcpy_h2d as a true asynchronous DMA source without another copy --
+ * the reference likewise decodes and memcpy's straight into its mapped staging buffer (LoadImageDataToBuffer,
+ * src/main.cpp:1105-1142).  Release with mid_image_free_pinned (never mid_image_free). */
+int  mid_image_load_pinned(mid_ctx *ctx, const char *path, mid_image *out);
+int  mid_image_free_pinned(mid_ctx *ctx, mid_image *img);
 int  mid_image_save(const char *path, const void *data, int32_t width, int32_t height, int32_t format);
 
 /* ---- measurement helper -----------------------------------------------------------------

@@ -396,3 +396,38 @@ def test_nlm_unusual_windows(ctx, search, patch):
     got = ctx.nlm_accum(t, nb, Z(29, 71), 0.45, search, patch)
     ref = oracle.nlm_accum(t, nb, Z(29, 71), 0.45, search, patch)
     assert rel_err(got, ref) < 5e-5, (search, patch)
+
+
+# ---- batched plain bilateral ------------------------------------------------------------------------
+@pytest.mark.parametrize("radius,layout", [(8, "linear"), (8, "texture"), (4, "texture"), (6, "linear"), (20, "texture")])
+def test_bilateral_batch_is_the_single_frame_call_repeated(ctx, radius, layout):
+    """mid_bilateral_batch (one launch, grid = tiles x frames) == mid_bilateral per frame, bit for bit: tuned radii,
+    a run-time radius (6) and both addressing rules; one frame is checked against the oracle."""
+    rng = np.random.default_rng(700 + radius)
+    h, w = 53, 141
+    frames = [synth_hdr(rng, h, w) for _ in range(5)]
+    got = ctx.bilateral_batch(frames, radius, 2.0, 0.2, layout)
+    for f, g in zip(frames, got):
+        assert np.array_equal(g, ctx.bilateral(f, radius, 2.0, 0.2, layout))
+    ref = (oracle.bilateral_linear if layout == "linear" else oracle.bilateral_texture)(frames[3], radius, 2.0, 0.2)
+    assert rel_err(got[3], ref) < BIL_TOL
+    ldr = [synth_ldr(rng, 40, 70) for _ in range(3)]
+    got8 = ctx.bilateral_batch(ldr, radius, 2.0, 0.2, layout)
+    assert all(np.array_equal(g, ctx.bilateral(f, radius, 2.0, 0.2, layout)) for f, g in zip(ldr, got8))
+
+
+def test_bilateral_batch_argument_errors(ctx):
+    import ctypes
+    img = np.zeros((8, 8, 4), np.float32)
+    d = ctx.upload(img)
+    o = ctx.alloc(8 * 8 * 16)
+    p = mid.BilateralParams(8, 8, 2.0, 0.2, 4, 0, 0)
+    one = (ctypes.c_void_p * 1)(d.ptr)
+    out = (ctypes.c_void_p * 1)(o.ptr)
+    assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), one, out, 0, None) == 1       # n_frames < 1
+    assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), one, one, 1, None) == 1       # in-place
+    assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), None, out, 1, None) == 1
+    nul = (ctypes.c_void_p * 1)(None)
+    assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), nul, out, 1, None) == 1
+    assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), one, out, 1, None) == 0
+    ctx.sync()

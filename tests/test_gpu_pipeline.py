@@ -108,3 +108,43 @@ def test_caller_owned_memory_can_be_pinned_in_place(ctx):
             assert mid.lib.mid_host_unregister(ctx.handle, f.ctypes.data) == 0
     assert mid.lib.mid_host_register(ctx.handle, None, 16) != 0
     assert mid.lib.mid_host_unregister(ctx.handle, None) != 0
+
+
+def test_frames_decoded_straight_into_pinned_memory(ctx, tmp_path):
+    """mid_image_load_pinned: the decoder writes into page-locked memory (no intermediate copy); pixels equal
+    mid_image_load's, the buffers feed the pipeline as they are, and a bad file releases what it allocated."""
+    import ctypes
+    import image_denoising_filter_amd as mid
+    from image_denoising_filter_amd._lib import Image
+    from conftest import synth_ldr
+    rng = np.random.default_rng(77)
+    frames = [synth_hdr(rng, 36, 72) * 0.3 for _ in range(4)]
+    ldr = synth_ldr(rng, 36, 72)
+    paths = []
+    for i, f in enumerate(frames):
+        paths.append(tmp_path / f"f_{i:04d}.exr")
+        mid.save_image(paths[-1], f)
+    mid.save_image(tmp_path / "l.png", ldr)
+    imgs = []
+    try:
+        for p in paths + [tmp_path / "l.png"]:
+            im = Image()
+            assert mid.lib.mid_image_load_pinned(ctx.handle, str(p).encode(), ctypes.byref(im)) == 0
+            imgs.append(im)
+        got = [np.ctypeslib.as_array(ctypes.cast(im.data, ctypes.POINTER(ctypes.c_float)), shape=(36, 72, 4)) for im in imgs[:4]]
+        assert all(np.array_equal(g, mid.load_image(p)) for g, p in zip(got, paths))
+        assert imgs[4].format == mid.FMT_RGBA8 and imgs[4].width == 72
+        g8 = np.ctypeslib.as_array(ctypes.cast(imgs[4].data, ctypes.POINTER(ctypes.c_uint8)), shape=(36, 72, 4))
+        assert np.array_equal(g8, ldr)
+        # the pinned frames are DMA sources as they are (pinned=False: the arrays' own memory is handed over)
+        outs, _ = ctx.sequence_nlm(got, k=1, pinned=False)
+        want = ctx.nlm_temporal(frames, k=1)
+        assert all(np.array_equal(a, b) for a, b in zip(outs, want))
+    finally:
+        for im in imgs:
+            assert mid.lib.mid_image_free_pinned(ctx.handle, ctypes.byref(im)) == 0
+    bad = tmp_path / "bad.exr"
+    bad.write_bytes(paths[0].read_bytes()[:200])
+    im = Image()
+    assert mid.lib.mid_image_load_pinned(ctx.handle, str(bad).encode(), ctypes.byref(im)) == 5 and not im.data
+    assert mid.lib.mid_image_load_pinned(ctx.handle, str(tmp_path / "nope.png").encode(), ctypes.byref(im)) == 5

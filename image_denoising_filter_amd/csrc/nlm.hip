@@ -35,9 +35,76 @@ struct NlmArgs {
     // fused temporal mode
     int n_frames, k, first, count;
     int out_u8;            // fused mode: outputs are RGBA8 frames (pack_rgba8) instead of float4
+    // gated mode of the frame pipeline (all NULL otherwise; see gate_wait): the launch is enqueued BEFORE its input
+    // frames have been uploaded, a workgroup starts on output t only once gate_ready[t+k] says the last frame of its
+    // window has landed, and the last workgroup of an output frame raises gate_host_done[frame] for the host.
+    const uint32_t *gate_ready;   // one word per entry of `frames` (device memory, written by the upload stream)
+    uint32_t *gate_done;          // one counter per output frame of this launch (device memory, zero on entry)
+    uint32_t *gate_host_done;     // one word per output frame (pinned host memory, polled by the pipeline thread)
+    uint32_t *gate_abort;         // device word: nonzero = give up (set by a workgroup whose wait timed out, or by the host)
     FrameTable frames;
     OutTable outs;
 };
+
+// ---- gating (frame pipeline) ---------------------------------------------------------------
+// Thread 0 of a workgroup waits until *flag != 0.  The word is written by the copy engine (a 4-byte H2D copy
+// queued behind the frame's own copy on the upload stream), so it is read with system-scope loads that bypass the
+// caches.  The frame itself needs no cache maintenance: a slot is written at most once per launch and never read
+// before its flag is up, and the launch started with invalidated caches -- no line of it can be resident.
+// EVERY wait is bounded (100 MHz wall clock): after kGateTimeoutTicks the workgroup raises *abort and leaves, and
+// every later wait sees the abort word at once -- the grid always drains, whatever the host does or fails to do.
+constexpr uint64_t kGateTimeoutTicks = 400000000ull;   // 4 s
+
+__device__ __forceinline__ bool gate_wait(const uint32_t *flag, uint32_t *abort_word)
+{
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return true;   // the common case: the upload is ahead
+    const uint64_t t0 = wall_clock64();
+    int naps = 1;                                   // back off to ~14 us between looks: up to 512 workgroups poll the same word
+    for (;;) {
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+        if (naps < 4) ++naps;
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return true;
+        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
+        if (wall_clock64() - t0 > kGateTimeoutTicks) {
+            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return false;
+        }
+    }
+}
+
+// Output stores of the gated mode: written THROUGH to memory (system scope), because the reader is the copy engine,
+// mid-kernel.  (A system-scope release fence instead -- write back the whole L2 -- cost 25 % of the kernel when every
+// workgroup did it: measured 0.74 against 0.585 ms per 1080p frame.)
+__device__ __forceinline__ void store_through(float4 *p, float4 v)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f r = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
+}
+__device__ __forceinline__ void store_through(uint32_t *p, uint32_t v)
+{
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// Whole workgroup: true = go on, false = abort (uniform).  Called before anything of the frames is read.
+__device__ __forceinline__ bool gate_enter(const NlmArgs &a, int table_index_of_last_frame)
+{
+    int bad = 0;
+    if (threadIdx.x == 0) bad = gate_wait(a.gate_ready + table_index_of_last_frame, a.gate_abort) ? 0 : 1;
+    return __syncthreads_or(bad) == 0;
+}
+
+// Whole workgroup, after its (write-through) output stores: every wave waits until its stores have been acknowledged,
+// then one thread counts the tile; the workgroup that completes the frame tells the host.
+__device__ __forceinline__ void gate_leave(const NlmArgs &a, int fz, unsigned tiles)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.gate_done + fz, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == tiles - 1u) __hip_atomic_store(a.gate_host_done + fz, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 // V[k] = D[k] + ... + D[k+PW-1] for k = 0..R-1, with the block decomposition of van Herk / Gil-Werman:
 // cut D into blocks of PW values, form running sums from each block's end (S) and from each block's start
@@ -84,7 +151,13 @@ __device__ __forceinline__ float horizontal_box(float v)
     return c;
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1>
+// SYM (tuning builds only, `make TUNING=1`, MID_NLM_VARIANT=7): the pair-symmetry ABLATION of DESIGN.md 3.1 -- for a
+// single frame d(p,s) = d(p+s,-s), so only the "positive" half of the offsets is evaluated and each weight is applied
+// twice: to p (as always) and, as w*T(p), to the partner pixel p+s through a mirror accumulator that moves one lane
+// per search column (DPP shift fused into the add).  This build measures the INSTRUCTION-MIX cost only: the mirror
+// sums are folded back into the wrong rows/lanes and contributions that would cross strip, wave-edge and tile borders
+// are dropped, so its output is wrong by construction -- it is an upper bound on what pair sharing could reach here.
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false>
 __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 {
     // SLO == SHI == 0 selects the run-time search range [a.slo, a.shi) (any window, same patch):
@@ -121,6 +194,10 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
     if (FUSED && MULTI) {
         f_lo = t_out - a.k < 0 ? 0 : t_out - a.k;
         f_hi = t_out + a.k > a.n_frames - 1 ? a.n_frames - 1 : t_out + a.k;
+    }
+
+    if (FUSED && a.gate_ready != nullptr) {      // frame pipeline: uploads are queued in frame order, so the window's last frame is the one to wait for
+        if (!gate_enter(a, f_hi)) return;        // uniform: the whole workgroup leaves
     }
 
     // Target column strip, kept in registers for every offset and every neighbour frame.
@@ -182,6 +259,73 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
             for (int m = 0; m < DR; ++m) n[m] = p[m * LW];
         };
 
+        if constexpr (SYM) {
+            float Ta[R];                                   // alpha of the lane's own centre texels (T carries rgb only)
+#pragma unroll
+            for (int k = 0; k < R; ++k) Ta[k] = fetch_texture<FMT>(target, w, h, gx, yb + k).w;
+            // mirror step: M moves one lane towards the partner column, then takes w * T(p)
+            auto compute_sym = [&](const float4 (&n)[DR], float4 (&M)[R], float (&Mw)[R]) {
+                float D[DR];
+#pragma unroll
+                for (int m = 0; m < DR; ++m) {
+                    const float dx = Tr[m] - n[m].x, dy = Tg[m] - n[m].y, dz = Tb[m] - n[m].z;
+                    D[m] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                }
+                float V[R];
+                vertical_box<PW, R>(D, V);
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const float d = horizontal_box<PLO, PHI>(V[k]);
+                    const float wt = __builtin_amdgcn_exp2f(-d);
+                    const float4 c = n[k + NL];
+                    acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
+                    acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
+                    accw[k] += wt;
+                    M[k].x = wave_shl1(M[k].x) + Tr[k + NL] * wt; M[k].y = wave_shl1(M[k].y) + Tg[k + NL] * wt;
+                    M[k].z = wave_shl1(M[k].z) + Tb[k + NL] * wt; M[k].w = wave_shl1(M[k].w) + Ta[k] * wt;
+                    Mw[k] = wave_shl1(Mw[k]) + wt;
+                }
+#pragma unroll
+                for (int m = 0; m < DR; ++m)
+                    if (m < NL || m >= NL + R) asm volatile("" ::"v"(n[m].w), "v"(accw[R - 1]));
+            };
+            {   // the zero offset has no partner
+                float4 n[DR];
+                load(n, lds + (wv * R - slo) * LW + lane - slo);
+                compute(n);
+            }
+            auto fold = [&](float4 (&M)[R], float (&Mw)[R]) {   // ABLATION: folded back in place (the real thing needs an LDS flush per row)
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    acc[k].x += M[k].x; acc[k].y += M[k].y; acc[k].z += M[k].z; acc[k].w += M[k].w;
+                    accw[k] += Mw[k];
+                    M[k] = make_float4(0.f, 0.f, 0.f, 0.f); Mw[k] = 0.f;
+                }
+            };
+            float4 M[R];
+            float Mw[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { M[k] = make_float4(0.f, 0.f, 0.f, 0.f); Mw[k] = 0.f; }
+            {   // search row 0: columns 1 .. shi-1 only
+                const float4 *rowp = lds + (wv * R - slo) * LW + lane;
+                for (int sx = 1 - slo; sx < SW; ++sx) {
+                    float4 n[DR];
+                    load(n, rowp + sx);
+                    compute_sym(n, M, Mw);
+                }
+                fold(M, Mw);
+            }
+            for (int sy = 1 - slo; sy < SW; ++sy) {       // search rows 1 .. shi-1, every column
+                const float4 *rowp = lds + (wv * R + sy) * LW + lane;
+#pragma unroll U
+                for (int sx = 0; sx < SW; ++sx) {
+                    float4 n[DR];
+                    load(n, rowp + sx);
+                    compute_sym(n, M, Mw);
+                }
+                fold(M, Mw);
+            }
+        } else
         for (int sy = 0; sy < SW; ++sy) {
             const float4 *rowp = lds + (wv * R + sy) * LW + lane;
 #pragma unroll U
@@ -205,27 +349,32 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
         if (!MULTI) break;
     }
 
-    if (!wave_active || lane < NL || lane > 63 - NR || gx >= w) return;
+    if (wave_active && lane >= NL && lane <= 63 - NR && gx < w) {
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int gy = yb + k;
-        if (gy >= h) break;
-        const size_t idx = (size_t)gy * w + gx;
-        if (FUSED) {
-            float4 o;
-            if (totw[k] == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);       // normalize.comp:36-38
-            else o = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
-            if (a.out_u8) ((uint32_t *)a.outs.p[fz])[idx] = pack_rgba8(o);
-            else ((float4 *)a.outs.p[fz])[idx] = o;
-        } else {
-            float4 *wp = (float4 *)(a.W + idx);
-            float4 wc = wp[0], nw = wp[1];
-            wc.x += tot[k].x; wc.y += tot[k].y; wc.z += tot[k].z; wc.w += tot[k].w;
-            nw.x += totw[k];
-            wp[0] = wc;
-            wp[1] = nw;
+        for (int k = 0; k < R; ++k) {
+            const int gy = yb + k;
+            if (gy >= h) break;
+            const size_t idx = (size_t)gy * w + gx;
+            if (FUSED) {
+                float4 o;
+                if (totw[k] == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);       // normalize.comp:36-38
+                else o = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
+                if (a.gate_ready != nullptr) {
+                    if (a.out_u8) store_through((uint32_t *)a.outs.p[fz] + idx, pack_rgba8(o));
+                    else store_through((float4 *)a.outs.p[fz] + idx, o);
+                } else if (a.out_u8) ((uint32_t *)a.outs.p[fz])[idx] = pack_rgba8(o);
+                else ((float4 *)a.outs.p[fz])[idx] = o;
+            } else {
+                float4 *wp = (float4 *)(a.W + idx);
+                float4 wc = wp[0], nw = wp[1];
+                wc.x += tot[k].x; wc.y += tot[k].y; wc.z += tot[k].z; wc.w += tot[k].w;
+                nw.x += totw[k];
+                wp[0] = wc;
+                wp[1] = nw;
+            }
         }
     }
+    if (FUSED && a.gate_ready != nullptr) gate_leave(a, fz, tiles);
 }
 
 // Any other search/patch ranges: one thread per pixel, straight from the shader text
@@ -235,7 +384,6 @@ template <int FMT, bool FUSED>
 __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int slo, int shi, int plo, int phi)
 {
     const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (px >= a.w || py >= a.h) return;
     const int fz = blockIdx.z, t_out = a.first + fz;
     const void *target = FUSED ? a.frames.p[t_out] : a.target;
     int f_lo = 0, f_hi = 0;
@@ -243,9 +391,13 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
         f_lo = t_out - a.k < 0 ? 0 : t_out - a.k;
         f_hi = t_out + a.k > a.n_frames - 1 ? a.n_frames - 1 : t_out + a.k;
     }
+    const bool gated = FUSED && a.gate_ready != nullptr;
+    if (gated && !gate_enter(a, f_hi)) return;
+    const bool inside = px < a.w && py < a.h;
+    if (!inside && !gated) return;
     float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
     float totw = 0.f;
-    for (int f = f_lo; f <= f_hi; ++f) {
+    for (int f = f_lo; inside && f <= f_hi; ++f) {
         const void *nb = FUSED ? a.frames.p[f] : a.neighbour;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         float accw = 0.001f;
@@ -268,23 +420,29 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
         tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w;
         totw += accw;
     }
-    const size_t idx = (size_t)py * a.w + px;
-    if (FUSED) {
-        float4 o;
-        if (totw == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);
-        else o = make_float4(tot.x / totw, tot.y / totw, tot.z / totw, tot.w / totw);
-        if (a.out_u8) ((uint32_t *)a.outs.p[fz])[idx] = pack_rgba8(o);
-        else ((float4 *)a.outs.p[fz])[idx] = o;
-    } else {
-        float4 *wp = (float4 *)(a.W + idx);
-        float4 wc = wp[0], nw = wp[1];
-        wc.x += tot.x; wc.y += tot.y; wc.z += tot.z; wc.w += tot.w;
-        nw.x += totw;
-        wp[0] = wc; wp[1] = nw;
+    if (inside) {
+        const size_t idx = (size_t)py * a.w + px;
+        if (FUSED) {
+            float4 o;
+            if (totw == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);
+            else o = make_float4(tot.x / totw, tot.y / totw, tot.z / totw, tot.w / totw);
+            if (gated) {
+                if (a.out_u8) store_through((uint32_t *)a.outs.p[fz] + idx, pack_rgba8(o));
+                else store_through((float4 *)a.outs.p[fz] + idx, o);
+            } else if (a.out_u8) ((uint32_t *)a.outs.p[fz])[idx] = pack_rgba8(o);
+            else ((float4 *)a.outs.p[fz])[idx] = o;
+        } else {
+            float4 *wp = (float4 *)(a.W + idx);
+            float4 wc = wp[0], nw = wp[1];
+            wc.x += tot.x; wc.y += tot.y; wc.z += tot.z; wc.w += tot.w;
+            nw.x += totw;
+            wp[0] = wc; wp[1] = nw;
+        }
     }
+    if (gated) gate_leave(a, fz, gridDim.x * gridDim.y);
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1>
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false>
 static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
 {
     constexpr bool RTS = (SLO == 0 && SHI == 0);
@@ -293,7 +451,7 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
     const int SW = RTS ? a.shi - a.slo : SHI - SLO;
     const int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + SW - 1;
     const size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
-    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U>;
+    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, SYM>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     // run-time-range instantiations are launched with different tile sizes: raise their limit to the device maximum once
@@ -328,6 +486,8 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
         if (!multi && variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, false, 3>(ctx, a, s);
         if (!multi && variant == 2) return launch_strip<-10, 11, -3, 4, 7, 12, FMT, FUSED, false, 3>(ctx, a, s);
         if (!multi && variant == 5) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7>(ctx, a, s);
+        if (!multi && variant == 7) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 1, true>(ctx, a, s);   // pair-symmetry ablation
+        if (!multi && variant == 8) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3, true>(ctx, a, s);
 #endif
         if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3>(ctx, a, s);
         return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s);
@@ -409,7 +569,7 @@ extern "C" int mid_nlm_temporal(mid_ctx *ctx, const mid_nlm_params *p, const voi
 }
 
 int mid::nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *const *frames, int n_frames, int k,
-                          int first, int count, void *const *out, int out_u8, void *stream)
+                          int first, int count, void *const *out, int out_u8, void *stream, const GateArgs *gate)
 {
     Bind b(ctx, stream);
     if (b.rc) return b.rc;
@@ -427,6 +587,12 @@ int mid::nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *con
         NlmArgs a{};
         a.w = p->width; a.h = p->height; set_scales(a, p->filteringParameter);
         a.n_frames = hi - lo + 1; a.k = k; a.first = c0 - lo; a.count = cn; a.out_u8 = out_u8;
+        if (gate) {
+            a.gate_ready = gate->ready + lo;                 // table entry i is frame lo + i
+            a.gate_done = gate->done + (c0 - first);         // output fz of this launch is output (c0 - first) + fz of the call
+            a.gate_host_done = gate->host_done + (c0 - first);
+            a.gate_abort = gate->abort;
+        }
         for (int f = lo; f <= hi; ++f) {
             MID_REQUIRE(frames[f] != nullptr, "nlm_temporal: frame %d is NULL", f);
             a.frames.p[f - lo] = frames[f];

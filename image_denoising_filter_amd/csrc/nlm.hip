@@ -73,8 +73,7 @@ __device__ __forceinline__ bool gate_wait(const uint32_t *flag, uint32_t *abort_
 }
 
 // Output stores of the gated mode: written THROUGH to memory (system scope), because the reader is the copy engine,
-// mid-kernel.  (A system-scope release fence instead -- write back the whole L2 -- cost 25 % of the kernel when every
-// workgroup did it: measured 0.74 against 0.585 ms per 1080p frame.)
+// mid-kernel; a system-scope release fence per workgroup (write the whole L2 back, 1156 times per frame) is the alternative.
 __device__ __forceinline__ void store_through(float4 *p, float4 v)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -86,23 +85,42 @@ __device__ __forceinline__ void store_through(uint32_t *p, uint32_t v)
     asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
 
-// Whole workgroup: true = go on, false = abort (uniform).  Called before anything of the frames is read.
-__device__ __forceinline__ bool gate_enter(const NlmArgs &a, int table_index_of_last_frame)
+// The other side of gate_wait: one thread, queued on the upload stream behind the frame's copy (a 4-byte
+// hipMemcpyAsync measured the same; the kernel keeps the copy engines free of tiny transfers).
+__global__ void gate_raise_kernel(uint32_t *flag) { store_through(flag, 1u); }
+
+// Whole workgroup: true = go on, false = abort (uniform).  Called before anything of the frames is read.  `word` is
+// any LDS word the workgroup does not use yet (the strip kernels lend the first word of their tile: no static LDS, so
+// the dynamic-LDS limit of the run-time-range instantiations stays the whole 160 KB).
+__device__ __forceinline__ bool gate_enter(const NlmArgs &a, int table_index_of_last_frame, volatile int *word)
 {
-    int bad = 0;
-    if (threadIdx.x == 0) bad = gate_wait(a.gate_ready + table_index_of_last_frame, a.gate_abort) ? 0 : 1;
-    return __syncthreads_or(bad) == 0;
+    if (threadIdx.x == 0) *word = gate_wait(a.gate_ready + table_index_of_last_frame, a.gate_abort) ? 1 : 0;
+    __syncthreads();
+    const bool ok = *word != 0;
+    __syncthreads();                                // everyone has read the word before the tile fill reuses it
+    return ok;
 }
 
 // Whole workgroup, after its (write-through) output stores: every wave waits until its stores have been acknowledged,
 // then one thread counts the tile; the workgroup that completes the frame tells the host.
-__device__ __forceinline__ void gate_leave(const NlmArgs &a, int fz, unsigned tiles)
+// The count is two-level: a frame's tiles are dealt over kGateFan sub-counters, each in its own 128-byte line, and the
+// tile that completes a sub-counter bumps the frame's top counter, so no single address takes 1156 device-scope
+// atomics per frame (a workgroup keeps its CU slot until its atomic has returned).
+constexpr unsigned kGateFan = 32, kGateLineWords = 32;
+constexpr unsigned kGateWordsPerFrame = (kGateFan + 1) * kGateLineWords;   // mid::kGateWordsPerFrame words of `done` per output frame
+
+__device__ __forceinline__ void gate_leave(const NlmArgs &a, int fz, unsigned tile, unsigned tiles)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(a.gate_done + fz, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == tiles - 1u) __hip_atomic_store(a.gate_host_done + fz, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t *base = a.gate_done + (size_t)fz * kGateWordsPerFrame;
+        const unsigned r = tile % kGateFan;
+        const unsigned mine = tiles / kGateFan + (r < tiles % kGateFan ? 1u : 0u);       // tiles dealt to sub-counter r
+        const unsigned used = tiles < kGateFan ? tiles : kGateFan;                      // sub-counters that receive any tile
+        if (__hip_atomic_fetch_add(base + (r + 1) * kGateLineWords, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1u)
+            if (__hip_atomic_fetch_add(base, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == used - 1u)
+                __hip_atomic_store(a.gate_host_done + fz, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -157,7 +175,8 @@ __device__ __forceinline__ float horizontal_box(float v)
 // per search column (DPP shift fused into the add).  This build measures the INSTRUCTION-MIX cost only: the mirror
 // sums are folded back into the wrong rows/lanes and contributions that would cross strip, wave-edge and tile borders
 // are dropped, so its output is wrong by construction -- it is an upper bound on what pair sharing could reach here.
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false>
+// GATED: the frame pipeline's launches (gate_wait above); plain launches are instantiated without any of it.
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, bool GATED = false>
 __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 {
     // SLO == SHI == 0 selects the run-time search range [a.slo, a.shi) (any window, same patch):
@@ -196,8 +215,8 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
         f_hi = t_out + a.k > a.n_frames - 1 ? a.n_frames - 1 : t_out + a.k;
     }
 
-    if (FUSED && a.gate_ready != nullptr) {      // frame pipeline: uploads are queued in frame order, so the window's last frame is the one to wait for
-        if (!gate_enter(a, f_hi)) return;        // uniform: the whole workgroup leaves
+    if constexpr (GATED) {                       // frame pipeline: uploads are queued in frame order, so the window's last frame is the one to wait for
+        if (!gate_enter(a, f_hi, (volatile int *)lds)) return;   // uniform: the whole workgroup leaves
     }
 
     // Target column strip, kept in registers for every offset and every neighbour frame.
@@ -359,7 +378,7 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
                 float4 o;
                 if (totw[k] == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);       // normalize.comp:36-38
                 else o = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
-                if (a.gate_ready != nullptr) {
+                if constexpr (GATED) {
                     if (a.out_u8) store_through((uint32_t *)a.outs.p[fz] + idx, pack_rgba8(o));
                     else store_through((float4 *)a.outs.p[fz] + idx, o);
                 } else if (a.out_u8) ((uint32_t *)a.outs.p[fz])[idx] = pack_rgba8(o);
@@ -374,15 +393,16 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
             }
         }
     }
-    if (FUSED && a.gate_ready != nullptr) gate_leave(a, fz, tiles);
+    if constexpr (GATED) gate_leave(a, fz, blockIdx.x - (unsigned)fz * tiles, tiles);
 }
 
 // Any other search/patch ranges: one thread per pixel, straight from the shader text
 // (nonlocal.comp:36-59) with global-memory fetches.  Correct for every legal parameter set;
 // not a tuned path.
-template <int FMT, bool FUSED>
+template <int FMT, bool FUSED, bool GATED = false>
 __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int slo, int shi, int plo, int phi)
 {
+    __shared__ int gate_word;                    // (no dynamic LDS in this kernel)
     const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
     const int fz = blockIdx.z, t_out = a.first + fz;
     const void *target = FUSED ? a.frames.p[t_out] : a.target;
@@ -391,8 +411,8 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
         f_lo = t_out - a.k < 0 ? 0 : t_out - a.k;
         f_hi = t_out + a.k > a.n_frames - 1 ? a.n_frames - 1 : t_out + a.k;
     }
-    const bool gated = FUSED && a.gate_ready != nullptr;
-    if (gated && !gate_enter(a, f_hi)) return;
+    constexpr bool gated = GATED;
+    if (gated && !gate_enter(a, f_hi, &gate_word)) return;
     const bool inside = px < a.w && py < a.h;
     if (!inside && !gated) return;
     float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
             wp[0] = wc; wp[1] = nw;
         }
     }
-    if (gated) gate_leave(a, fz, gridDim.x * gridDim.y);
+    if (gated) gate_leave(a, fz, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
 }
 
 template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false>
@@ -451,7 +471,8 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
     const int SW = RTS ? a.shi - a.slo : SHI - SLO;
     const int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + SW - 1;
     const size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
-    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, SYM>;
+    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, SYM, false>;
+    if constexpr (FUSED && !SYM) { if (a.gate_ready) kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, false, true>; }
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     // run-time-range instantiations are launched with different tile sizes: raise their limit to the device maximum once
@@ -511,8 +532,9 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
 #undef MID_NLM_RT
     }
     dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16), FUSED ? a.count : 1);
-    hipLaunchKernelGGL((nlm_generic_kernel<FMT, FUSED>), grid, dim3(256), 0, s, a,
-                       p->search_lo, p->search_hi, p->patch_lo, p->patch_hi);
+    auto gkern = nlm_generic_kernel<FMT, FUSED, false>;
+    if constexpr (FUSED) { if (a.gate_ready) gkern = nlm_generic_kernel<FMT, FUSED, true>; }
+    hipLaunchKernelGGL(gkern, grid, dim3(256), 0, s, a, p->search_lo, p->search_hi, p->patch_lo, p->patch_hi);
     MID_HIP(hipGetLastError());
     return MID_OK;
 }
@@ -527,6 +549,13 @@ static int check_params(const mid_nlm_params *p)
                 "nlm: half-open ranges [lo,hi) must contain 0");
     MID_REQUIRE(p->search_hi - p->search_lo <= 64 && p->patch_hi - p->patch_lo <= 16, "nlm: window too large");
     MID_REQUIRE(p->format == MID_FMT_RGBA32F || p->format == MID_FMT_RGBA8, "nlm: unknown format %d", p->format);
+    return MID_OK;
+}
+
+int gate_raise(uint32_t *flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(gate_raise_kernel, dim3(1), dim3(1), 0, s, flag);
+    MID_HIP(hipGetLastError());
     return MID_OK;
 }
 
@@ -589,7 +618,7 @@ int mid::nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *con
         a.n_frames = hi - lo + 1; a.k = k; a.first = c0 - lo; a.count = cn; a.out_u8 = out_u8;
         if (gate) {
             a.gate_ready = gate->ready + lo;                 // table entry i is frame lo + i
-            a.gate_done = gate->done + (c0 - first);         // output fz of this launch is output (c0 - first) + fz of the call
+            a.gate_done = gate->done + (size_t)(c0 - first) * kGateWordsPerFrame;   // output fz of this launch is output (c0 - first) + fz of the call
             a.gate_host_done = gate->host_done + (c0 - first);
             a.gate_abort = gate->abort;
         }

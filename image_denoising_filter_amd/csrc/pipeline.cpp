@@ -56,16 +56,22 @@ struct DeviceBufs {
 
 }  // namespace
 
-// ---- gated pipeline -------------------------------------------------------------------------------------------
-// The overlapped form of the frame pipeline.  Measured on MI355X: what limits the event-joined pipeline above is that
-// a 1080p frame is 2.26 rounds of workgroups -- one launch per frame costs 0.75 ms against 0.585 ms per frame inside a
-// 16-frame launch, and two launches co-running on two streams still take 0.70 ms per frame.  So the launches are made
-// LARGE again (up to kGateChunk output frames each) and the dependency on the uploads moves from the launch (an event
-// the whole launch would have to wait for) into the kernel: the launch is enqueued straight away, a workgroup of output
-// t waits on a device word the upload stream raises behind frame t+k's copy (csrc/nlm.hip, gate_wait: bounded spin),
-// and the workgroup that finishes the last tile of an output frame raises a word in pinned host memory; this thread
-// sees it and queues that frame's download.  Frames therefore flow upload -> filter -> download one by one although
-// the kernel launches are chunk-sized, and the CUs never drain between frames.
+// ---- gated pipeline (opt-in: MID_PIPE_GATED=1) ------------------------------------------------------------------
+// A second schedule for the same job, built to test whether the per-frame launches of the event-joined pipeline below
+// cost throughput (a 1080p frame is 2.26 rounds of workgroups: one launch per frame takes 0.75 ms against 0.585 ms per
+// frame inside a 16-frame launch).  Here the launches are chunk-sized (up to kGateChunk output frames) and the
+// dependency on the uploads moves from the launch into the kernel: the launch is enqueued straight away, a workgroup
+// of output t waits on a device word the upload stream raises behind frame t+k's copy (csrc/nlm.hip, gate_wait: bounded
+// spin), and the workgroup that finishes the last tile of an output frame raises a word in pinned host memory; this
+// thread sees it and queues that frame's download.  Frames flow upload -> filter -> download one by one although the
+// launches are chunk-sized, and the CUs never drain between frames.
+// MEASURED (tools/pipe_gated_ab.py, 1080p, 21x21/7x7, k=0): no gain.  16 frames: RGBA8 2812 vs 2821 Mpixel/s event-joined,
+// RGBA32F 2609 vs 2565; 64 frames: 3261 vs 3249 and 2854 vs 2847.  The two co-running per-frame launches of the
+// event-joined pipeline already keep the CUs full (at 64 frames it runs at 0.638 ms per frame = the 0.584 ms of a warm
+// 64-frame launch plus the clock ramp below), and what separates the 16-frame figures from the kernel's batched rate is
+// the GPU's clock ramp after idle: ONE 64-frame launch takes 36.8 ms back to back and 39.6 ms after 50 ms of idle.
+// The event-joined pipeline therefore stays the default (no spinning workgroups, no mid-kernel visibility rules);
+// this one is kept, tested bit for bit against it, as the measured alternative.
 //
 // Invariants the kernel relies on (kept here by construction):
 //   * uploads are queued in frame order on ONE stream, each followed by its flag write, so "flag of frame f is up"
@@ -107,10 +113,11 @@ static int sequence_gated(mid_ctx *ctx, const mid_nlm_params *p, const void *con
     DeviceBufs dring, dout, dflags;
     if (int rc = dring.make(RS, in_bytes)) return rc;
     if (int rc = dout.make(OS, dl_bytes)) return rc;
-    // device words: ready[n_up] | done[count] | abort
-    const size_t n_words = (size_t)n_up + count + 1;
+    // device words: ready[n_up] | abort | pad to a 128-byte line | done[count][kGateDoneWordsPerFrame]
+    const size_t done_off = ((size_t)n_up + 1 + 31) / 32 * 32;
+    const size_t n_words = done_off + (size_t)count * kGateDoneWordsPerFrame;
     if (int rc = dflags.make(1, n_words * sizeof(uint32_t))) return rc;
-    uint32_t *ready = (uint32_t *)dflags.p[0], *done = ready + n_up, *abort_w = done + count;
+    uint32_t *ready = (uint32_t *)dflags.p[0], *abort_w = ready + n_up, *done = ready + done_off;
     HostBuf hflags;                                                   // host_done[count] | one | abort read-back
     if (int rc = hflags.make(((size_t)count + 2) * sizeof(uint32_t))) return rc;
     volatile uint32_t *host_done = (volatile uint32_t *)hflags.p;
@@ -147,7 +154,7 @@ static int sequence_gated(mid_ctx *ctx, const mid_nlm_params *p, const void *con
         MID_HIP(hipMemcpyAsync(slot(f), host_frames[f], in_bytes, hipMemcpyHostToDevice, ctx->upload));
         MID_HIP(hipEventRecord(up1.ev[f - f_lo], ctx->upload));
         // the gate: queued behind the frame's own copy on the same stream
-        MID_HIP(hipMemcpyAsync(ready + (f - f_lo), one, sizeof(uint32_t), hipMemcpyHostToDevice, ctx->upload));
+        if (int rc = gate_raise(ready + (f - f_lo), ctx->upload)) return rc;
         return MID_OK;
     };
     auto launch_chunk = [&](int j) -> int {                           // the launch goes first: it needs no upload to be queued, only the slots' addresses
@@ -159,7 +166,7 @@ static int sequence_gated(mid_ctx *ctx, const mid_nlm_params *p, const void *con
         for (int f = lo; f <= need; ++f) tbl[f - lo] = slot(f);
         void *o[kMaxFrames];
         for (int i = 0; i < cn; ++i) o[i] = dout.p[(c0 - first + i) % OS];
-        GateArgs g{ready + (lo - f_lo), done + (c0 - first), (uint32_t *)host_done + (c0 - first), abort_w};
+        GateArgs g{ready + (lo - f_lo), done + (size_t)(c0 - first) * kGateDoneWordsPerFrame, (uint32_t *)host_done + (c0 - first), abort_w};
         MID_HIP(hipEventRecord(k0.ev[j], ctx->compute));
         if (int rc = nlm_temporal_out(ctx, p, tbl, need - lo + 1, k, c0 - lo, cn, o, out_u8 ? 1 : 0, ctx->compute, &g)) return rc;
         MID_HIP(hipEventRecord(k1.ev[j], ctx->compute));
@@ -259,10 +266,10 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
     for (int i = f_lo; i <= f_hi; ++i) MID_REQUIRE(host_frames[i], "sequence_nlm: frame %d is NULL", i);
     for (int i = 0; i < count; ++i) MID_REQUIRE(host_out[i], "sequence_nlm: output %d is NULL", i);
 
-    // overlap: the gated pipeline above (MID_PIPE_GATED=0 keeps the event-joined one below for A/B measurements)
+    // MID_PIPE_GATED=1 selects the gated schedule above (same results bit for bit, measured no faster)
     {
         const char *e = getenv("MID_PIPE_GATED");
-        if (overlap && !(e && e[0] == '0')) return sequence_gated(ctx, p, host_frames, n, k, first, count, host_out, out_u8, timings_ms);
+        if (overlap && e && e[0] == '1') return sequence_gated(ctx, p, host_frames, n, k, first, count, host_out, out_u8, timings_ms);
     }
 
     const size_t npix = (size_t)p->width * p->height;

@@ -154,7 +154,7 @@ def test_frames_decoded_straight_into_pinned_memory(ctx, tmp_path):
 def test_gated_pipeline_with_many_chunks(ctx, k, n, chunk, monkeypatch):
     """The gated pipeline (csrc/pipeline.cpp: chunk-sized launches enqueued before their uploads, workgroups gated on
     per-frame device words, per-frame completion words polled by the host) with SMALL chunks, so that every mechanism
-    is exercised many times on a short sequence: input slots recycled (RS = 2*chunk + 2k), output slots recycled two
+    (opt-in: MID_PIPE_GATED=1) is exercised many times on a short sequence: input slots recycled (RS = 2*chunk + 2k), output slots recycled two
     chunks later, launches chained.  Must equal the direct temporal call bit for bit -- float and u8 outputs, whole
     sequence and a sub-range -- and the event-joined pipeline (MID_PIPE_GATED=0) must give the same bits."""
     rng = np.random.default_rng(7000 + n)
@@ -162,6 +162,7 @@ def test_gated_pipeline_with_many_chunks(ctx, k, n, chunk, monkeypatch):
     frames = [(synth_hdr(rng, h, w) * 0.25).astype(np.float32) for _ in range(n)]
     direct = ctx.nlm_temporal(frames, k=k)
     monkeypatch.setenv("MID_PIPE_CHUNK", str(chunk))
+    monkeypatch.setenv("MID_PIPE_GATED", "1")
     outs, (wall, kern, copy) = ctx.sequence_nlm(frames, k=k, overlap=True)
     assert all(np.array_equal(a, b) for a, b in zip(outs, direct)) and wall > 0 and kern > 0 and copy > 0
     part, _ = ctx.sequence_nlm(frames, k=k, overlap=True, first=2, count=n - 5, pinned=False)
@@ -173,8 +174,9 @@ def test_gated_pipeline_with_many_chunks(ctx, k, n, chunk, monkeypatch):
     assert all(np.array_equal(a, b) for a, b in zip(ev, direct))
 
 
-def test_gated_pipeline_generic_kernel_and_other_windows(ctx):
+def test_gated_pipeline_generic_kernel_and_other_windows(ctx, monkeypatch):
     """Windows without a strip instantiation run the one-thread-per-pixel kernel: gated the same way."""
+    monkeypatch.setenv("MID_PIPE_GATED", "1")
     rng = np.random.default_rng(7100)
     frames = [(synth_hdr(rng, 30, 50) * 0.25).astype(np.float32) for _ in range(7)]
     for search, patch in (((-4, 5), (-2, 2)), ((-7, 8), (-2, 3)), ((-7, 7), (-3, 3))):

@@ -64,3 +64,33 @@ def test_a3_a5_layer_guided_with_layer_equal_image_equals_the_reference_run(ctx,
     img, _, _, _ = _fix(name)
     fl = ctx.bilateral_layers(img, [u8], R, 10.0, 0.2)
     assert rel_err(fl[R:h - R, R:w - R], out[R:h - R, R:w - R]) < TOL
+
+
+# ---- a4: the nearest thing to an anchor the reference allows ------------------------------------------------------
+def _ramp(h, w):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    return np.stack([0.2 + 0.004 * xx + 0.001 * yy, 0.9 - 0.002 * xx + 0.003 * yy, 0.5 + 0.0015 * xx - 0.0025 * yy,
+                     np.ones_like(xx)], -1).astype(np.float32)
+
+
+@pytest.mark.parametrize("patch", [(-3, 4), (-3, 3), (-1, 2)])
+def test_a4_nlm_on_a_linear_ramp_is_the_anchored_bilateral(ctx, patch):
+    """The reference has no CPU NLM, so a4 cannot be held against reference-run output.  What CAN be done: on an image
+    that is linear in x and y every patch tap sees the same colour difference, d(p,s) = P^2 * |I(p) - I(p+s)|^2
+    (P^2 = number of patch taps, nonlocal.comp:42-52: a plain sum over the half-open patch), so nonlocal.comp's weight
+    exp(-d/h^2) is bialteral.comp's range weight with sigma_c = h / sqrt(2 P^2) and no spatial term -- and the GPU
+    bilateral IS anchored to the reference run (tests above).  This pins, through a1: the tap count of the half-open
+    patch range, the exponent, the search window, the 4-channel weighted sum, and the 0.001 the shader adds to the norm
+    (nonlocal.comp:32)."""
+    h, w, R, hp = 60, 76, 6, 0.5
+    img = _ramp(h, w)
+    P2 = (patch[1] - patch[0]) ** 2
+    Wn = ctx.nlm_accum(img, img, np.zeros((h, w, 8), np.float32), hp, (-R, R + 1), patch)
+    bil = ctx.bilateral(img, R, 1e6, hp / np.sqrt(2.0 * P2), "texture")
+    m = R + max(-patch[0], patch[1])                        # away from the zero texels beyond the border
+    sw = Wn[m:-m, m:-m, 4].astype(np.float64) - 0.001       # sum of weights without the shader's bias
+    got = Wn[m:-m, m:-m, :4].astype(np.float64) / sw[..., None]
+    assert rel_err(got, bil[m:-m, m:-m]) < 2e-5
+    # and the fused form: normalize divides by (0.001 + sum w)
+    out = ctx.nlm_temporal([img], k=0, hparam=hp, search=(-R, R + 1), patch=patch)[0]
+    assert rel_err(out[m:-m, m:-m], bil[m:-m, m:-m].astype(np.float64) * (sw / (sw + 0.001))[..., None]) < 2e-5

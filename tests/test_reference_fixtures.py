@@ -89,3 +89,20 @@ def test_config0_cli_writes_the_references_png(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         got = mid.load_image(tmp_path / "output-cpu.png")
         assert got.shape == (512, 512, 4) and np.array_equal(got, g["out_u8"]), f"{threads} thread(s)"
+
+
+@pytest.mark.parametrize("patch", [(-3, 4), (-3, 3)])
+def test_oracle_nlm_on_a_linear_ramp_is_the_pinned_bilateral_formula(patch):
+    """The same identity as tests/test_gpu_reference_anchor.py::test_a4_..., on the checker: on a linear ramp
+    oracle.nlm_accum (restating nonlocal.comp) must equal oracle.bilateral_texture (pinned to reference-run output above)
+    with sigma_c = h / sqrt(2 P^2) and no spatial term, up to the 0.001 norm bias."""
+    h, w, R, hp = 40, 52, 5, 0.5
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([0.2 + 0.004 * xx + 0.001 * yy, 0.9 - 0.002 * xx + 0.003 * yy, 0.5 + 0.0015 * xx - 0.0025 * yy,
+                    np.ones_like(xx)], -1).astype(np.float32)
+    P2 = (patch[1] - patch[0]) ** 2
+    Wn = oracle.nlm_accum(img, img, np.zeros((h, w, 8), np.float32), hp, (-R, R + 1), patch, threads=4)
+    bil = oracle.bilateral_texture(img, R, 1e6, hp / np.sqrt(2.0 * P2))
+    m = R + max(-patch[0], patch[1])
+    sw = Wn[m:-m, m:-m, 4].astype(np.float64) - 0.001
+    assert rel_err(Wn[m:-m, m:-m, :4].astype(np.float64) / sw[..., None], bil[m:-m, m:-m]) < 2e-5

@@ -597,11 +597,13 @@ def main():
                 # clock ramp after idle (about 2.8 ms per cold start, tools/pipe_gated_ab.py) weigh a quarter as much
                 hf = [f.cpu().numpy() for f in frames]
                 lf = [np.clip(f * 64.0, 0, 255).astype(np.uint8) for f in hf] * (SEQ_FRAMES // F)
-                _, (wall8, kern8, copy8) = ctx.sequence_nlm(lf, k=0, overlap=True, search=SEARCH, patch=PATCH, out_u8=True)
+                for _rep in range(2):       # the second pass is reported: the first one also pays for first-use of the larger buffers
+                    _, (wall8, kern8, copy8) = ctx.sequence_nlm(lf, k=0, overlap=True, search=SEARCH, patch=PATCH, out_u8=True)
                 also["pipeline_pcie_inclusive_ldr_64"] = {"Mpixel/s_overlap": round(len(lf) * NPIX / 1e3 / wall8, 1), "frames": len(lf),
                                                           "kernel_ms": round(kern8, 3), "copy_ms": round(copy8, 3)}
                 hf = hf * (SEQ_FRAMES // F)
-                _, (wall, kern, copy) = ctx.sequence_nlm(hf, k=0, overlap=True, search=SEARCH, patch=PATCH)
+                for _rep in range(2):
+                    _, (wall, kern, copy) = ctx.sequence_nlm(hf, k=0, overlap=True, search=SEARCH, patch=PATCH)
                 also["pipeline_pcie_inclusive_64"] = {"Mpixel/s_overlap": round(len(hf) * NPIX / 1e3 / wall, 1), "frames": len(hf),
                                                       "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3)}
 

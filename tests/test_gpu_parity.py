@@ -431,3 +431,12 @@ def test_bilateral_batch_argument_errors(ctx):
     assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), nul, out, 1, None) == 1
     assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), one, out, 1, None) == 0
     ctx.sync()
+
+
+def test_bilateral_batch_chunks_beyond_the_frame_table(ctx):
+    """More frames than the by-value frame table holds (96): several launches, same bits."""
+    rng = np.random.default_rng(811)
+    frames = [synth_hdr(rng, 20, 70) for _ in range(101)]
+    got = ctx.bilateral_batch(frames, 4, 2.0, 0.2, "texture")
+    for i in (0, 1, 95, 96, 97, 100):
+        assert np.array_equal(got[i], ctx.bilateral(frames[i], 4, 2.0, 0.2, "texture")), i

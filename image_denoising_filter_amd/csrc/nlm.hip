@@ -221,12 +221,19 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
 
     // Target column strip, kept in registers for every offset and every neighbour frame.
     float Tr[DR], Tg[DR], Tb[DR];
+#ifdef MID_NLM_PKD   // tuning experiment: red/green differences as one v_pk_add_f32
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f Trg[DR];
+#endif
 #pragma unroll
     for (int m = 0; m < DR; ++m) {
         // Colours are pre-multiplied by sqrt(log2(e))/h, so the patch distance IS the exp2 argument and the
         // multiply per (pixel, offset) disappears; the accumulated colours are unscaled once per frame.
         const float4 t = fetch_texture<FMT>(target, w, h, gx, yb + PLO + m);
         Tr[m] = t.x * a.sk; Tg[m] = t.y * a.sk; Tb[m] = t.z * a.sk;
+#ifdef MID_NLM_PKD
+        Trg[m] = v2f{Tr[m], Tg[m]};
+#endif
     }
 
     float4 tot[R];
@@ -251,7 +258,12 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
             float D[DR];
 #pragma unroll
             for (int m = 0; m < DR; ++m) {
+#ifdef MID_NLM_PKD
+                const v2f d2 = Trg[m] - v2f{n[m].x, n[m].y};
+                const float dx = d2.x, dy = d2.y, dz = Tb[m] - n[m].z;
+#else
                 const float dx = Tr[m] - n[m].x, dy = Tg[m] - n[m].y, dz = Tb[m] - n[m].z;
+#endif
                 D[m] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
             }
             float V[R];

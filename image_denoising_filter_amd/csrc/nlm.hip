@@ -176,8 +176,13 @@ __device__ __forceinline__ float horizontal_box(float v)
 // sums are folded back into the wrong rows/lanes and contributions that would cross strip, wave-edge and tile borders
 // are dropped, so its output is wrong by construction -- it is an upper bound on what pair sharing could reach here.
 // GATED: the frame pipeline's launches (gate_wait above); plain launches are instantiated without any of it.
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, bool GATED = false>
-__global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
+// SYP > 0: the search window is walked in passes of SYP search rows, the LDS tile holding only the rows one pass needs
+// (TILE_H + PW-1 + SYP-1 instead of TILE_H + PW-1 + SW-1).  At 21x21/7x7 with SYP = 3 the tile is 84 x 40 texels = 52.5 KB,
+// so THREE workgroups share a CU (3 waves per SIMD instead of 2; the kernel needs 166 VGPRs when asked to, no spill).  The
+// offsets are visited in the same order (search row outer, search column inner), so the sums -- and the output bits --
+// are those of the single-pass kernel.
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, bool GATED = false, int SYP = 0>
+__global__ __launch_bounds__(NW * 64, SYP > 0 ? 3 : 1) void nlm_strip_kernel(const NlmArgs a)
 {
     // SLO == SHI == 0 selects the run-time search range [a.slo, a.shi) (any window, same patch):
     // LDS pitch and loop bounds then come from the arguments instead of being folded constants.
@@ -190,8 +195,10 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
     const int slo = RTS ? a.slo : SLO;
     const int SW = RTS ? a.shi - a.slo : SHI - SLO;
     const int LW = 64 + SW - 1;
-    const int LH = TILE_H + PW - 1 + SW - 1;
+    const int SYPASS = SYP > 0 ? SYP : SW;                       // search rows per tile fill
+    const int LH = TILE_H + PW - 1 + SYPASS - 1;
     static_assert(PLO <= 0 && PHI >= 1 && (RTS || SHI - SLO >= 1), "ranges must contain 0");
+    static_assert(!(SYP > 0 && SYM), "the symmetry ablation is single-pass");
 
     extern __shared__ float4 lds[];
 
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
         __syncthreads();   // previous frame's readers are done with the tile
         fill_tile<FMT, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo, tid, NW * 64, a.sk);
         __syncthreads();
-        if (!wave_active) continue;
+        if (SYP == 0 && !wave_active) continue;   // (multi-pass: every wave must reach the barriers of the later passes)
 
         float4 acc[R];
         float accw[R];
@@ -355,6 +362,26 @@ __global__ __launch_bounds__(NW * 64) void nlm_strip_kernel(const NlmArgs a)
                     compute_sym(n, M, Mw);
                 }
                 fold(M, Mw);
+            }
+        } else if constexpr (SYP > 0) {
+            for (int sy0 = 0; sy0 < SW; sy0 += SYP) {          // one tile fill per SYP search rows; same offset order as the single pass
+                if (sy0 > 0) {
+                    __syncthreads();
+                    fill_tile<FMT, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo + sy0, tid, NW * 64, a.sk);
+                    __syncthreads();
+                }
+                if (wave_active) {
+                    const int sy1 = sy0 + SYP < SW ? sy0 + SYP : SW;
+                    for (int sy = sy0; sy < sy1; ++sy) {
+                        const float4 *rowp = lds + (wv * R + sy - sy0) * LW + lane;
+#pragma unroll U
+                        for (int sx = 0; sx < SW; ++sx) {
+                            float4 n[DR];
+                            load(n, rowp + sx);
+                            compute(n);
+                        }
+                    }
+                }
             }
         } else
         for (int sy = 0; sy < SW; ++sy) {
@@ -474,17 +501,17 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
     if (gated) gate_leave(a, fz, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false>
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0>
 static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
 {
     constexpr bool RTS = (SLO == 0 && SHI == 0);
     constexpr int PW = PHI - PLO;
     constexpr int VW = 64 - (PW - 1), TILE_H = NW * R;
     const int SW = RTS ? a.shi - a.slo : SHI - SLO;
-    const int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + SW - 1;
+    const int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + (SYP > 0 ? SYP : SW) - 1;
     const size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
-    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, SYM, false>;
-    if constexpr (FUSED && !SYM) { if (a.gate_ready) kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, false, true>; }
+    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, SYM, false, SYP>;
+    if constexpr (FUSED && !SYM) { if (a.gate_ready) kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, false, true, SYP>; }
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     // run-time-range instantiations are launched with different tile sizes: raise their limit to the device maximum once
@@ -521,6 +548,14 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
         if (!multi && variant == 5) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7>(ctx, a, s);
         if (!multi && variant == 7) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 1, true>(ctx, a, s);   // pair-symmetry ablation
         if (!multi && variant == 8) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3, true>(ctx, a, s);
+        if (variant == 9) {   // three workgroups per CU: 7 passes of 3 search rows (52.5 KB tile)
+            if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3, false, 3>(ctx, a, s);
+            return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3, false, 3>(ctx, a, s);
+        }
+        if (variant == 10) {  // the same passes, 7 search columns unrolled
+            if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 7, false, 3>(ctx, a, s);
+            return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7, false, 3>(ctx, a, s);
+        }
 #endif
         if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3>(ctx, a, s);
         return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s);

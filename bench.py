@@ -325,16 +325,25 @@ def main():
         # a launcher that disagrees with --gpus is a set-up error, not something to paper over with a 1-GPU number
         print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MID_BENCH_REHEARSE=1: a rehearsal of the N-rank flow on a box with FEWER GPUs than ranks -- ranks share devices,
+    # the process group is gloo (RCCL refuses two ranks on one device), halo frames are staged through host memory.  Real
+    # kernels, real control flow, no xGMI: the JSON line says so ("rehearsal": true) and is never a scaling measurement.
+    rehearse = os.environ.get("MID_BENCH_REHEARSE") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    coll_device = torch.device("cpu") if rehearse else device        # where the small tensors of the collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         world = dist.get_world_size()           # n_gpus is what the process group says, not what the flags say
 
     import image_denoising_filter_amd as mid
     from image_denoising_filter_amd import sharding
-    ctx = mid.Context(local_rank)
+    ctx = mid.Context(dev_index)
     # One explicit (non-default) stream for everything: torch ops, RCCL waits (req.wait() orders the CURRENT
     # torch stream), the library's kernels and the hipEvents that time them.  The default stream's handle is
     # 0, which the C-ABI reads as "use the context's own stream" -- that would not be ordered after RCCL.
@@ -384,7 +393,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = timers.ms()
@@ -399,6 +408,7 @@ def main():
         "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        **({"rehearsal": True, "rehearsal_note": f"{world} ranks on {torch.cuda.device_count()} device(s), gloo + host-staged halo: control flow only, not a scaling measurement"} if rehearse else {}),
         "config": {"workload": workload,
                    "frames_per_gpu_per_step": F, "width": W, "height": H, "h": HPARAM,
                    "parallelism": f"frame-sharded x{world}, no data-path collective"},
@@ -550,7 +560,7 @@ def main():
             te = (time.perf_counter() - t1) / reps
             per_rank = [te, held / reps, float(stats.get("halo_bytes_recv", 0)), float(stats.get("halo_bytes_sent", 0))]
             if world > 1:
-                t = torch.tensor(per_rank, device=device, dtype=torch.float64)
+                t = torch.tensor(per_rank, device=coll_device, dtype=torch.float64)
                 allr = [torch.empty_like(t) for _ in range(world)]
                 dist.all_gather(allr, t)
                 rows = [[float(x) for x in a.tolist()] for a in allr]

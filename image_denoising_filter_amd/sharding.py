@@ -62,56 +62,61 @@ def halo_plan(n_frames: int, world: int, k: int, rank: int):
 def exchange_halo(local: Sequence[torch.Tensor], n_frames: int, k: int, group=None):
     """Returns {global frame id: tensor} for every frame this rank needs (its own block + halo).
     `local` are this rank's frames in order.  One batch of isend/irecv; no-op for world_size 1 or k 0."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    start, count = partition(n_frames, world)[rank]
-    if len(local) != count:
-        raise ValueError(f"rank {rank} owns {count} frames, got {len(local)}")
-    have = {start + i: t for i, t in enumerate(local)}
-    if world == 1 or k == 0:
-        return have
-    recv, send = halo_plan(n_frames, world, k, rank)
-    proto = local[0] if count else None
-    ops = []
-    for peer, ids in recv:
-        for f in ids:
-            buf = torch.empty_like(proto)
-            have[f] = buf
-            ops.append(dist.P2POp(dist.irecv, buf, peer, group=group, tag=f))
-    for peer, ids in send:
-        for f in ids:
-            ops.append(dist.P2POp(dist.isend, have[f], peer, group=group, tag=f))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+    have, reqs = start_halo_exchange(local, n_frames, k, group)
+    for req in reqs:
+        req.wait()
+    if have.finalize:
+        have.finalize()
+    if reqs:
         _order_after_halo(local)
     return have
+
+
+class _Have(dict):
+    """{global frame id: tensor}; `finalize` (when set) must be called after the requests have been waited for -- it
+    moves halo frames that were staged through host memory onto the device."""
+    finalize = None
+
+
+def _must_stage(tensor, group):
+    """Device tensors cannot travel over a backend that only moves host memory (gloo): stage them through the host."""
+    return bool(getattr(tensor, "is_cuda", False)) and dist.is_initialized() and dist.get_backend(group) == "gloo"
 
 
 def start_halo_exchange(local: Sequence[torch.Tensor], n_frames: int, k: int, group=None):
     """Non-blocking form of exchange_halo: posts the isend/irecv batch and returns (have, requests).
     `have` already contains this rank's own frames; halo entries are valid only after every request
-    in `requests` has been waited for."""
+    in `requests` has been waited for (and `have.finalize()` has run, if it is set).
+    With backend "nccl" (RCCL) device tensors go GPU to GPU over xGMI.  With "gloo" and device tensors the frames are
+    staged through host memory on both sides (a rehearsal path: one GPU box, several ranks on one device)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     start, count = partition(n_frames, world)[rank]
     if len(local) != count:
         raise ValueError(f"rank {rank} owns {count} frames, got {len(local)}")
-    have = {start + i: t for i, t in enumerate(local)}
+    have = _Have((start + i, t) for i, t in enumerate(local))
     if world == 1 or k == 0 or count == 0:
-        if world > 1 and k > 0:      # an empty block still has to serve nobody and receive nothing
-            pass
         return have, []
     recv, send = halo_plan(n_frames, world, k, rank)
-    ops = []
+    stage = _must_stage(local[0], group)
+    ops, staged = [], []
     for peer, ids in recv:
         for f in ids:
-            buf = torch.empty_like(local[0])
-            have[f] = buf
+            buf = torch.empty(local[0].shape, dtype=local[0].dtype, device="cpu") if stage else torch.empty_like(local[0])
+            if stage:
+                staged.append((f, buf))
+            else:
+                have[f] = buf
             ops.append(dist.P2POp(dist.irecv, buf, peer, group=group, tag=f))
     for peer, ids in send:
         for f in ids:
-            ops.append(dist.P2POp(dist.isend, have[f], peer, group=group, tag=f))
+            ops.append(dist.P2POp(dist.isend, have[f].cpu() if stage else have[f], peer, group=group, tag=f))
+    if stage:
+        def finalize():
+            for f, buf in staged:
+                have[f] = buf.to(local[0].device)
+            torch.cuda.current_stream(local[0].device).synchronize()     # the launches that follow may use any stream
+        have.finalize = finalize
     return have, (dist.batch_isend_irecv(ops) if ops else [])
 
 
@@ -174,6 +179,8 @@ def temporal_block_overlapped(launch, local: Sequence[torch.Tensor], n_frames: i
         hooks["before_wait"]()
     for r in reqs:
         r.wait()
+    if have.finalize:
+        have.finalize()
     if reqs:
         _order_after_halo(local)
     if "after_wait" in hooks:

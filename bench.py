@@ -19,6 +19,12 @@ import os
 import sys
 import time
 
+# dmabuf IPC between the per-GPU processes: this pool's host driver supports nothing else (the build brief's environment
+# notes: "without it RCCL / CUDA-tensor sharing across processes fails with hipIpcGetMemHandle: invalid argument"; the
+# variable is already exported on the GPU boxes).  Set here, before anything can initialise the HSA runtime, so that the
+# self-launcher, `torch.distributed.run ... bench.py` and a plain 1-GPU run all see the same setting.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -78,6 +84,28 @@ def load_traffic(frames_per_launch):
                                                      "WRITE_SIZE passes of this command, read back -- not measured in this run")
     except Exception as e:  # noqa: BLE001
         return None, f"unreadable profile: {e}"
+
+
+def load_utilisation(workload):
+    """Counter-derived utilisation of the dominant kernel (VALU issue, LDS, stall share), read back from the committed
+    profiles/r*_utilisation.json exactly like `traffic` -- PMC counters cannot be read inside an un-profiled run.
+    tools/summarize_profiles.py writes that file from the rocprofv3 --pmc passes of this command and states every
+    unit; `utilisation_source` names the file and its date."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_utilisation.json")))
+    if not cands:
+        return {"valu_util": None, "lds_util": None, "utilisation_source": "no profiles/r*_utilisation.json"}
+    try:
+        u = json.load(open(cands[-1]))
+        k = u["kernels"]["nlm_bench" if workload == "nlm" else "bilateral_r8_linear"]
+        return {"valu_util": k["valu_issue_util"], "lds_util": k["lds_util"],
+                "valu_active_share_of_wave_cycles": k["valu_active_share_of_wave_cycles"],
+                "issue_stall_share_of_wave_cycles": k["issue_stall_share_of_wave_cycles"],
+                "lds_bank_conflict_cycles": k["lds_bank_conflict_cycles"],
+                "utilisation_source": f"profiles/{os.path.basename(cands[-1])} ({u.get('date')}): rocprofv3 --pmc passes of this "
+                                      "command, read back -- not measured in this run; definitions and units in that file"}
+    except Exception as e:  # noqa: BLE001
+        return {"valu_util": None, "lds_util": None, "utilisation_source": f"unreadable profile: {e}"}
 
 
 class Timers:
@@ -255,7 +283,7 @@ def launch_ranks(n):
     import subprocess
     env = dict(os.environ)
     env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this host driver
+    # (HSA_ENABLE_IPC_MODE_LEGACY is set at the top of this module for every way of starting it; the children inherit it)
     env.setdefault("OMP_NUM_THREADS", "1")
     procs = []
     for r in range(n):
@@ -351,6 +379,13 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
+    process_group = None
+    if world > 1:
+        # what the ranks actually run on: the process group's backend and every rank's device, in the line itself
+        names = [None] * world
+        dist.all_gather_object(names, f"cuda:{dev_index} {ctx.name}")
+        process_group = {"backend": str(dist.get_backend()), "devices": names,
+                         "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
 
     def barrier():
         if world > 1:
@@ -411,13 +446,17 @@ def main():
         **({"rehearsal": True, "rehearsal_note": f"{world} ranks on {torch.cuda.device_count()} device(s), gloo + host-staged halo: control flow only, not a scaling measurement"} if rehearse else {}),
         "config": {"workload": workload,
                    "frames_per_gpu_per_step": F, "width": W, "height": H, "h": HPARAM,
-                   "parallelism": f"frame-sharded x{world}, no data-path collective"},
+                   "parallelism": f"frame-sharded x{world}, no data-path collective",
+                   **({"process_group": process_group} if process_group else {})},
         "roofline": {
             "bound": "mfma", "bound_actual": "valu", "achieved": round(flop_px * px_per_launch / avg_launch_s / 1e12, 3),
             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop_px * px_per_launch / avg_launch_s / 1e12 / PEAK_FP32_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": kernel, "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+            # spread of the K timed launches (hipEvent pairs on the launch stream, one pair per step)
+            "kernel_ms_min": round(min(kernel_ms) / launches_per_step, 4), "kernel_ms_max": round(max(kernel_ms) / launches_per_step, 4),
+            **load_utilisation(args.workload),
             "note": "compute roofline (`bound` keeps the contract's enum; bound_actual says what binds): the kernel is fp32-VALU bound and issues no MFMA; the peak is the fp32 "
                     "vector peak, which equals the dense f32 MFMA peak on gfx950 (157.3 TFLOP/s). Algorithmic "
                     f"flops = {flop_note} x px per launch.",
@@ -604,14 +643,16 @@ def main():
         def extra_pipeline_long():
             if rank == 0 and world == 1:
                 # the same pipeline over a 64-frame sequence (the length of BASELINE configs[4]): fill, drain and the GPU's
-                # clock ramp after idle (about 2.8 ms per cold start, tools/pipe_gated_ab.py) weigh a quarter as much
+                # clock ramp after idle (about 2.8 ms per cold start, tools/pipe_idle_ab.py) weigh a quarter as much
+                # exactly SEQ_FRAMES frames whatever --frames is: the F resident frames cycled (the keys say _64)
                 hf = [f.cpu().numpy() for f in frames]
-                lf = [np.clip(f * 64.0, 0, 255).astype(np.uint8) for f in hf] * (SEQ_FRAMES // F)
+                lf8 = [np.clip(f * 64.0, 0, 255).astype(np.uint8) for f in hf]
+                lf = [lf8[i % F] for i in range(SEQ_FRAMES)]
                 for _rep in range(2):       # the second pass is reported: the first one also pays for first-use of the larger buffers
                     _, (wall8, kern8, copy8) = ctx.sequence_nlm(lf, k=0, overlap=True, search=SEARCH, patch=PATCH, out_u8=True)
                 also["pipeline_pcie_inclusive_ldr_64"] = {"Mpixel/s_overlap": round(len(lf) * NPIX / 1e3 / wall8, 1), "frames": len(lf),
                                                           "kernel_ms": round(kern8, 3), "copy_ms": round(copy8, 3)}
-                hf = hf * (SEQ_FRAMES // F)
+                hf = [hf[i % F] for i in range(SEQ_FRAMES)]
                 for _rep in range(2):
                     _, (wall, kern, copy) = ctx.sequence_nlm(hf, k=0, overlap=True, search=SEARCH, patch=PATCH)
                 also["pipeline_pcie_inclusive_64"] = {"Mpixel/s_overlap": round(len(hf) * NPIX / 1e3 / wall, 1), "frames": len(hf),

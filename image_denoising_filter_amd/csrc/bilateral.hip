@@ -461,9 +461,20 @@ extern "C" int mid_bilateral_batch(mid_ctx *ctx, const mid_bilateral_params *p, 
     if (int rc = check_params(p, "bilateral_batch")) return rc;
     MID_REQUIRE(in && out, "bilateral_batch: NULL table");
     MID_REQUIRE(n_frames >= 1, "bilateral_batch: n_frames %d < 1", n_frames);
-    for (int i = 0; i < n_frames; ++i) {
-        MID_REQUIRE(in[i] && out[i], "bilateral_batch: frame %d is NULL", i);
-        MID_REQUIRE((const void *)in[i] != (const void *)out[i], "bilateral_batch: in-place filtering is not supported (frame %d)", i);
+    {
+        // All frames of a launch run concurrently: an output that is ANY frame's input (not only its own) would be
+        // written while other workgroups still read it -- ping-pong tables shifted by one slot, say.  Reject it.
+        std::unordered_set<const void *> inputs;
+        for (int i = 0; i < n_frames; ++i) {
+            MID_REQUIRE(in[i] && out[i], "bilateral_batch: frame %d is NULL", i);
+            inputs.insert(in[i]);
+        }
+        std::unordered_set<const void *> outputs;
+        for (int i = 0; i < n_frames; ++i) {
+            MID_REQUIRE(!inputs.count((const void *)out[i]),
+                        "bilateral_batch: out[%d] is also an input frame of this call (in-place / aliased filtering is not supported)", i);
+            MID_REQUIRE(outputs.insert((const void *)out[i]).second, "bilateral_batch: out[%d] appears twice", i);
+        }
     }
     const bool lin = p->layout == MID_LAYOUT_LINEAR, u8 = p->format == MID_FMT_RGBA8;
     for (int c0 = 0; c0 < n_frames; c0 += kMaxFrames) {          // one launch per kMaxFrames frames

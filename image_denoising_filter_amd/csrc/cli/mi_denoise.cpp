@@ -57,6 +57,7 @@ struct Options {
     std::string modes = "all";      // comma list of: bilateral,layers,linear,nlm,multiframe,overlap
     bool animation = false;         // new capability: temporal NLM of EVERY frame of the sequence
     int gpus = 1;                   // animation mode: frame blocks over this many devices
+    long pinned_mb = 16384;         // animation mode: at most this much page-locked host memory (inputs + outputs); the rest is pageable
 };
 
 #define MID_CHECK(call)                                                                          \
@@ -290,24 +291,45 @@ public:
         // place 25.1 ms.  Page-locking is per process, so the one context used for loading serves every device.
         mid_ctx *io = nullptr;
         MID_CHECK(mid_ctx_create(opt.device, &io));
-        struct Pinned {                                   // owns the pinned frames and outputs; released before `io`
+        // Page-locked memory is a bounded resource: at most --pinned-mb of it (default 16 GiB, inputs and outputs
+        // together) is requested, and a frame whose pinned allocation fails -- or that would exceed the budget -- is
+        // decoded into ordinary pageable memory instead (the pipeline accepts both; HIP then stages that copy and its
+        // overlap is lost, nothing else changes).  A long or high-resolution sequence degrades, it does not abort.
+        struct Pinned {                                   // owns the frames and outputs (pinned or pageable); released before `io`
             mid_ctx *c;
             std::vector<mid_image> frames;
+            std::vector<char> frame_pinned;
             std::vector<void *> outs;
+            std::vector<char> out_pinned;
             ~Pinned()
             {
-                for (auto &f : frames) (void)mid_image_free_pinned(c, &f);
-                for (auto o : outs) (void)mid_free_host(c, o);
+                for (size_t i = 0; i < frames.size(); ++i) {
+                    if (frame_pinned[i]) (void)mid_image_free_pinned(c, &frames[i]);
+                    else mid_image_free(&frames[i]);
+                }
+                for (size_t i = 0; i < outs.size(); ++i) {
+                    if (out_pinned[i]) (void)mid_free_host(c, outs[i]);
+                    else free(outs[i]);
+                }
                 mid_ctx_destroy(c);
             }
-        } pin{io, {}, {}};
+        } pin{io, {}, {}, {}, {}};
+        const size_t pinned_budget = (size_t)std::max(0l, opt.pinned_mb) << 20;
+        size_t pinned_bytes = 0, frame_bytes_guess = 0;
+        int n_pageable = 0;
         const auto tl0 = std::chrono::steady_clock::now();
         for (auto &f : frameNames) {
             mid_image img{};
-            if (mid_image_load_pinned(io, f.c_str(), &img)) throw std::runtime_error(mid_last_error());
+            // inputs and outputs share the budget frame by frame: input i is pinned only if output i can be as well
+            bool pinned = pinned_bytes + 2 * frame_bytes_guess <= pinned_budget;
+            if (pinned && mid_image_load_pinned(io, f.c_str(), &img)) pinned = false;      // no page-locked memory left (or a bad file: the pageable load below reports that)
+            if (!pinned && mid_image_load(f.c_str(), &img)) throw std::runtime_error(mid_last_error());
             pin.frames.push_back(img);
+            pin.frame_pinned.push_back(pinned ? 1 : 0);
             if (img.width != pin.frames[0].width || img.height != pin.frames[0].height || img.format != pin.frames[0].format)
                 throw std::runtime_error(f + ": size/format differs from the first frame");
+            frame_bytes_guess = (size_t)img.width * img.height * (img.format == MID_FMT_RGBA32F ? 16 : 4);
+            if (pinned) pinned_bytes += 2 * frame_bytes_guess; else ++n_pageable;
         }
         const double load_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
         const int w = pin.frames[0].width, h = pin.frames[0].height, fmt = pin.frames[0].format;
@@ -319,9 +341,19 @@ public:
         for (int i = 0; i < n; ++i) {
             in[i] = pin.frames[i].data;
             void *o = nullptr;
-            MID_CHECK(mid_alloc_host(io, out_bytes, &o));
+            bool pinned = pin.frame_pinned[i] != 0;
+            if (pinned && mid_alloc_host(io, out_bytes, &o)) { pinned = false; o = nullptr; }
+            if (!pinned) {
+                o = malloc(out_bytes);
+                if (!o) throw std::runtime_error("out of host memory for the output frames");
+                if (pin.frame_pinned[i]) ++n_pageable;
+            }
             pin.outs.push_back(o);
+            pin.out_pinned.push_back(pinned ? 1 : 0);
         }
+        if (n_pageable)
+            std::cout << "	" << n_pageable << " frame(s) beyond the page-locked budget (--pinned-mb " << opt.pinned_mb
+                      << ") use pageable host memory: their copies are staged by HIP and do not overlap\n";
         const int G = std::max(1, std::min(opt.gpus, n));
         // One context per device, created -- and its code object, streams and allocator warmed by filtering two tiny
         // frames -- BEFORE the clock starts: the timed region below is the frame pipeline itself (uploads, kernels,
@@ -449,6 +481,8 @@ static void usage()
         "  --temporal-k K            multiframe: frames t-K..t+K of the sorted sequence instead of the reference's list\n"
         "  --animation               denoise EVERY sibling frame with temporal NLM (window +-K, default 2) instead of the mode list\n"
         "  --gpus N                  animation mode: split the sequence into N frame blocks, one per device\n"
+        "  --pinned-mb M             animation mode: page-lock at most M MiB of host memory for frames in and out (default 16384);\n"
+        "                            frames beyond that, or whose page-locked allocation fails, use pageable memory\n"
         "  --cpu-radius R --cpu-sigma-s S --cpu-sigma-c C   CPU path (default 10 10.0 0.2)\n"
         "  --cpu-threads A,B         thread counts of the CPU runs (default 1,8)\n"
         "  --cpu-fix-blue            use the blue channel in the CPU range distance (the reference does not)\n";
@@ -478,6 +512,7 @@ int main(int argc, char **argv)
         else if (a == "--temporal-k") opt.temporal_k = atoi(next());
         else if (a == "--animation") opt.animation = true;
         else if (a == "--gpus") opt.gpus = atoi(next());
+        else if (a == "--pinned-mb") opt.pinned_mb = atol(next());
         else if (a == "--cpu-radius") opt.cpu_radius = atoi(next());
         else if (a == "--cpu-sigma-s") opt.cpu_sigma_s = (float)atof(next());
         else if (a == "--cpu-sigma-c") opt.cpu_sigma_c = (float)atof(next());

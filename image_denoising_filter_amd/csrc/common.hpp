@@ -51,21 +51,8 @@ inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 // mid_nlm_temporal with the output format as an argument: out_u8 != 0 writes RGBA8 frames (pack_rgba8 of the
 // normalized pixel) instead of float4 ones -- used by the frame pipeline's u8 variant, not exported.
-//
-// gate != nullptr selects the gated mode of the frame pipeline (csrc/pipeline.cpp, csrc/nlm.hip gate_wait): the launch
-// may be enqueued before its frames are uploaded; ready[f] (device word per frame of `frames`, absolute index) is
-// raised by the upload stream, done[i] / host_done[i] (per output of this call, index relative to `first`) count
-// finished tiles and tell the host when output i is complete; *abort makes every waiting workgroup leave.
-constexpr size_t kGateDoneWordsPerFrame = 33 * 32;   // two-level tile counter of one output frame (csrc/nlm.hip, gate_leave)
-struct GateArgs {
-    const uint32_t *ready;
-    uint32_t *done;        // kGateDoneWordsPerFrame words per output
-    uint32_t *host_done;
-    uint32_t *abort;
-};
 int nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *const *frames, int n_frames, int k,
-                     int first, int count, void *const *out, int out_u8, void *stream, const GateArgs *gate = nullptr);
-int gate_raise(uint32_t *flag, hipStream_t s);   // *flag = 1 (written through to memory) in stream order
+                     int first, int count, void *const *out, int out_u8, void *stream);
 
 // Raise the dynamic-LDS limit of `kern` once per context (kernels here use up to 160 KB).
 inline int ensure_lds(mid_ctx *ctx, const void *kern, size_t bytes)

@@ -35,94 +35,9 @@ struct NlmArgs {
     // fused temporal mode
     int n_frames, k, first, count;
     int out_u8;            // fused mode: outputs are RGBA8 frames (pack_rgba8) instead of float4
-    // gated mode of the frame pipeline (all NULL otherwise; see gate_wait): the launch is enqueued BEFORE its input
-    // frames have been uploaded, a workgroup starts on output t only once gate_ready[t+k] says the last frame of its
-    // window has landed, and the last workgroup of an output frame raises gate_host_done[frame] for the host.
-    const uint32_t *gate_ready;   // one word per entry of `frames` (device memory, written by the upload stream)
-    uint32_t *gate_done;          // one counter per output frame of this launch (device memory, zero on entry)
-    uint32_t *gate_host_done;     // one word per output frame (pinned host memory, polled by the pipeline thread)
-    uint32_t *gate_abort;         // device word: nonzero = give up (set by a workgroup whose wait timed out, or by the host)
     FrameTable frames;
     OutTable outs;
 };
-
-// ---- gating (frame pipeline) ---------------------------------------------------------------
-// Thread 0 of a workgroup waits until *flag != 0.  The word is written by the copy engine (a 4-byte H2D copy
-// queued behind the frame's own copy on the upload stream), so it is read with system-scope loads that bypass the
-// caches.  The frame itself needs no cache maintenance: a slot is written at most once per launch and never read
-// before its flag is up, and the launch started with invalidated caches -- no line of it can be resident.
-// EVERY wait is bounded (100 MHz wall clock): after kGateTimeoutTicks the workgroup raises *abort and leaves, and
-// every later wait sees the abort word at once -- the grid always drains, whatever the host does or fails to do.
-constexpr uint64_t kGateTimeoutTicks = 400000000ull;   // 4 s
-
-__device__ __forceinline__ bool gate_wait(const uint32_t *flag, uint32_t *abort_word)
-{
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return true;   // the common case: the upload is ahead
-    const uint64_t t0 = wall_clock64();
-    int naps = 1;                                   // back off to ~14 us between looks: up to 512 workgroups poll the same word
-    for (;;) {
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-        if (naps < 4) ++naps;
-        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return true;
-        if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return false;
-        if (wall_clock64() - t0 > kGateTimeoutTicks) {
-            __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            return false;
-        }
-    }
-}
-
-// Output stores of the gated mode: written THROUGH to memory (system scope), because the reader is the copy engine,
-// mid-kernel; a system-scope release fence per workgroup (write the whole L2 back, 1156 times per frame) is the alternative.
-__device__ __forceinline__ void store_through(float4 *p, float4 v)
-{
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f r = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
-}
-__device__ __forceinline__ void store_through(uint32_t *p, uint32_t v)
-{
-    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-}
-
-// The other side of gate_wait: one thread, queued on the upload stream behind the frame's copy (a 4-byte
-// hipMemcpyAsync measured the same; the kernel keeps the copy engines free of tiny transfers).
-__global__ void gate_raise_kernel(uint32_t *flag) { store_through(flag, 1u); }
-
-// Whole workgroup: true = go on, false = abort (uniform).  Called before anything of the frames is read.  `word` is
-// any LDS word the workgroup does not use yet (the strip kernels lend the first word of their tile: no static LDS, so
-// the dynamic-LDS limit of the run-time-range instantiations stays the whole 160 KB).
-__device__ __forceinline__ bool gate_enter(const NlmArgs &a, int table_index_of_last_frame, volatile int *word)
-{
-    if (threadIdx.x == 0) *word = gate_wait(a.gate_ready + table_index_of_last_frame, a.gate_abort) ? 1 : 0;
-    __syncthreads();
-    const bool ok = *word != 0;
-    __syncthreads();                                // everyone has read the word before the tile fill reuses it
-    return ok;
-}
-
-// Whole workgroup, after its (write-through) output stores: every wave waits until its stores have been acknowledged,
-// then one thread counts the tile; the workgroup that completes the frame tells the host.
-// The count is two-level: a frame's tiles are dealt over kGateFan sub-counters, each in its own 128-byte line, and the
-// tile that completes a sub-counter bumps the frame's top counter, so no single address takes 1156 device-scope
-// atomics per frame (a workgroup keeps its CU slot until its atomic has returned).
-constexpr unsigned kGateFan = 32, kGateLineWords = 32;
-constexpr unsigned kGateWordsPerFrame = (kGateFan + 1) * kGateLineWords;   // mid::kGateWordsPerFrame words of `done` per output frame
-
-__device__ __forceinline__ void gate_leave(const NlmArgs &a, int fz, unsigned tile, unsigned tiles)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t *base = a.gate_done + (size_t)fz * kGateWordsPerFrame;
-        const unsigned r = tile % kGateFan;
-        const unsigned mine = tiles / kGateFan + (r < tiles % kGateFan ? 1u : 0u);       // tiles dealt to sub-counter r
-        const unsigned used = tiles < kGateFan ? tiles : kGateFan;                      // sub-counters that receive any tile
-        if (__hip_atomic_fetch_add(base + (r + 1) * kGateLineWords, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1u)
-            if (__hip_atomic_fetch_add(base, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == used - 1u)
-                __hip_atomic_store(a.gate_host_done + fz, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
 
 // V[k] = D[k] + ... + D[k+PW-1] for k = 0..R-1, with the block decomposition of van Herk / Gil-Werman:
 // cut D into blocks of PW values, form running sums from each block's end (S) and from each block's start
@@ -175,14 +90,14 @@ __device__ __forceinline__ float horizontal_box(float v)
 // per search column (DPP shift fused into the add).  This build measures the INSTRUCTION-MIX cost only: the mirror
 // sums are folded back into the wrong rows/lanes and contributions that would cross strip, wave-edge and tile borders
 // are dropped, so its output is wrong by construction -- it is an upper bound on what pair sharing could reach here.
-// GATED: the frame pipeline's launches (gate_wait above); plain launches are instantiated without any of it.
 // SYP > 0: the search window is walked in passes of SYP search rows, the LDS tile holding only the rows one pass needs
 // (TILE_H + PW-1 + SYP-1 instead of TILE_H + PW-1 + SW-1).  At 21x21/7x7 with SYP = 3 the tile is 84 x 40 texels = 52.5 KB,
 // so THREE workgroups share a CU (3 waves per SIMD instead of 2; the kernel needs 166 VGPRs when asked to, no spill).  The
 // offsets are visited in the same order (search row outer, search column inner), so the sums -- and the output bits --
 // are those of the single-pass kernel.
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, bool GATED = false, int SYP = 0>
-__global__ __launch_bounds__(NW * 64, SYP > 0 ? 3 : 1) void nlm_strip_kernel(const NlmArgs a)
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SYP > 0 ? 3 : 1, SYP > 0 ? 3 : 2)))
+void nlm_strip_kernel(const NlmArgs a)
 {
     // SLO == SHI == 0 selects the run-time search range [a.slo, a.shi) (any window, same patch):
     // LDS pitch and loop bounds then come from the arguments instead of being folded constants.
@@ -220,10 +135,6 @@ __global__ __launch_bounds__(NW * 64, SYP > 0 ? 3 : 1) void nlm_strip_kernel(con
     if (FUSED && MULTI) {
         f_lo = t_out - a.k < 0 ? 0 : t_out - a.k;
         f_hi = t_out + a.k > a.n_frames - 1 ? a.n_frames - 1 : t_out + a.k;
-    }
-
-    if constexpr (GATED) {                       // frame pipeline: uploads are queued in frame order, so the window's last frame is the one to wait for
-        if (!gate_enter(a, f_hi, (volatile int *)lds)) return;   // uniform: the whole workgroup leaves
     }
 
     // Target column strip, kept in registers for every offset and every neighbour frame.
@@ -417,10 +328,7 @@ __global__ __launch_bounds__(NW * 64, SYP > 0 ? 3 : 1) void nlm_strip_kernel(con
                 float4 o;
                 if (totw[k] == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);       // normalize.comp:36-38
                 else o = make_float4(tot[k].x / totw[k], tot[k].y / totw[k], tot[k].z / totw[k], tot[k].w / totw[k]);
-                if constexpr (GATED) {
-                    if (a.out_u8) store_through((uint32_t *)a.outs.p[fz] + idx, pack_rgba8(o));
-                    else store_through((float4 *)a.outs.p[fz] + idx, o);
-                } else if (a.out_u8) ((uint32_t *)a.outs.p[fz])[idx] = pack_rgba8(o);
+                if (a.out_u8) ((uint32_t *)a.outs.p[fz])[idx] = pack_rgba8(o);
                 else ((float4 *)a.outs.p[fz])[idx] = o;
             } else {
                 float4 *wp = (float4 *)(a.W + idx);
@@ -432,16 +340,14 @@ __global__ __launch_bounds__(NW * 64, SYP > 0 ? 3 : 1) void nlm_strip_kernel(con
             }
         }
     }
-    if constexpr (GATED) gate_leave(a, fz, blockIdx.x - (unsigned)fz * tiles, tiles);
 }
 
 // Any other search/patch ranges: one thread per pixel, straight from the shader text
 // (nonlocal.comp:36-59) with global-memory fetches.  Correct for every legal parameter set;
 // not a tuned path.
-template <int FMT, bool FUSED, bool GATED = false>
+template <int FMT, bool FUSED>
 __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int slo, int shi, int plo, int phi)
 {
-    __shared__ int gate_word;                    // (no dynamic LDS in this kernel)
     const int px = blockIdx.x * 16 + (threadIdx.x & 15), py = blockIdx.y * 16 + (threadIdx.x >> 4);
     const int fz = blockIdx.z, t_out = a.first + fz;
     const void *target = FUSED ? a.frames.p[t_out] : a.target;
@@ -450,10 +356,8 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
         f_lo = t_out - a.k < 0 ? 0 : t_out - a.k;
         f_hi = t_out + a.k > a.n_frames - 1 ? a.n_frames - 1 : t_out + a.k;
     }
-    constexpr bool gated = GATED;
-    if (gated && !gate_enter(a, f_hi, &gate_word)) return;
     const bool inside = px < a.w && py < a.h;
-    if (!inside && !gated) return;
+    if (!inside) return;
     float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
     float totw = 0.f;
     for (int f = f_lo; inside && f <= f_hi; ++f) {
@@ -485,10 +389,7 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
             float4 o;
             if (totw == 0.0f) o = make_float4(1.f, 0.f, 1.f, 1.f);
             else o = make_float4(tot.x / totw, tot.y / totw, tot.z / totw, tot.w / totw);
-            if (gated) {
-                if (a.out_u8) store_through((uint32_t *)a.outs.p[fz] + idx, pack_rgba8(o));
-                else store_through((float4 *)a.outs.p[fz] + idx, o);
-            } else if (a.out_u8) ((uint32_t *)a.outs.p[fz])[idx] = pack_rgba8(o);
+            if (a.out_u8) ((uint32_t *)a.outs.p[fz])[idx] = pack_rgba8(o);
             else ((float4 *)a.outs.p[fz])[idx] = o;
         } else {
             float4 *wp = (float4 *)(a.W + idx);
@@ -498,7 +399,6 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
             wp[0] = wc; wp[1] = nw;
         }
     }
-    if (gated) gate_leave(a, fz, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
 }
 
 template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0>
@@ -510,8 +410,7 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
     const int SW = RTS ? a.shi - a.slo : SHI - SLO;
     const int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + (SYP > 0 ? SYP : SW) - 1;
     const size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
-    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, SYM, false, SYP>;
-    if constexpr (FUSED && !SYM) { if (a.gate_ready) kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, false, true, SYP>; }
+    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, SYM, SYP>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     // run-time-range instantiations are launched with different tile sizes: raise their limit to the device maximum once
@@ -556,6 +455,11 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
             if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 7, false, 3>(ctx, a, s);
             return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7, false, 3>(ctx, a, s);
         }
+        // six-wave workgroups (round 3): two workgroups per CU are already 3 waves/SIMD, with 5 (SYP = 5: 84 x 58 texels,
+        // 76.1 KB) or 3 (SYP = 7: 84 x 60, 78.8 KB) tile fills per frame instead of the 7 of variants 9/10
+        if (!multi && variant == 11) return launch_strip<-10, 11, -3, 4, 8, 6, FMT, FUSED, false, 3, false, 5>(ctx, a, s);
+        if (!multi && variant == 12) return launch_strip<-10, 11, -3, 4, 8, 6, FMT, FUSED, false, 3, false, 7>(ctx, a, s);
+        if (!multi && variant == 13) return launch_strip<-10, 11, -3, 4, 8, 6, FMT, FUSED, false, 7, false, 7>(ctx, a, s);
 #endif
         if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3>(ctx, a, s);
         return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s);
@@ -579,9 +483,7 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
 #undef MID_NLM_RT
     }
     dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16), FUSED ? a.count : 1);
-    auto gkern = nlm_generic_kernel<FMT, FUSED, false>;
-    if constexpr (FUSED) { if (a.gate_ready) gkern = nlm_generic_kernel<FMT, FUSED, true>; }
-    hipLaunchKernelGGL(gkern, grid, dim3(256), 0, s, a, p->search_lo, p->search_hi, p->patch_lo, p->patch_hi);
+    hipLaunchKernelGGL((nlm_generic_kernel<FMT, FUSED>), grid, dim3(256), 0, s, a, p->search_lo, p->search_hi, p->patch_lo, p->patch_hi);
     MID_HIP(hipGetLastError());
     return MID_OK;
 }
@@ -596,13 +498,6 @@ static int check_params(const mid_nlm_params *p)
                 "nlm: half-open ranges [lo,hi) must contain 0");
     MID_REQUIRE(p->search_hi - p->search_lo <= 64 && p->patch_hi - p->patch_lo <= 16, "nlm: window too large");
     MID_REQUIRE(p->format == MID_FMT_RGBA32F || p->format == MID_FMT_RGBA8, "nlm: unknown format %d", p->format);
-    return MID_OK;
-}
-
-int gate_raise(uint32_t *flag, hipStream_t s)
-{
-    hipLaunchKernelGGL(gate_raise_kernel, dim3(1), dim3(1), 0, s, flag);
-    MID_HIP(hipGetLastError());
     return MID_OK;
 }
 
@@ -645,7 +540,7 @@ extern "C" int mid_nlm_temporal(mid_ctx *ctx, const mid_nlm_params *p, const voi
 }
 
 int mid::nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *const *frames, int n_frames, int k,
-                          int first, int count, void *const *out, int out_u8, void *stream, const GateArgs *gate)
+                          int first, int count, void *const *out, int out_u8, void *stream)
 {
     Bind b(ctx, stream);
     if (b.rc) return b.rc;
@@ -663,12 +558,6 @@ int mid::nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *con
         NlmArgs a{};
         a.w = p->width; a.h = p->height; set_scales(a, p->filteringParameter);
         a.n_frames = hi - lo + 1; a.k = k; a.first = c0 - lo; a.count = cn; a.out_u8 = out_u8;
-        if (gate) {
-            a.gate_ready = gate->ready + lo;                 // table entry i is frame lo + i
-            a.gate_done = gate->done + (size_t)(c0 - first) * kGateWordsPerFrame;   // output fz of this launch is output (c0 - first) + fz of the call
-            a.gate_host_done = gate->host_done + (c0 - first);
-            a.gate_abort = gate->abort;
-        }
         for (int f = lo; f <= hi; ++f) {
             MID_REQUIRE(frames[f] != nullptr, "nlm_temporal: frame %d is NULL", f);
             a.frames.p[f - lo] = frames[f];

@@ -127,7 +127,9 @@ int mid_bilateral(mid_ctx *ctx, const mid_bilateral_params *p,
 /* The same dispatch for n_frames independent frames of one size in ONE launch (grid = tiles x frames): what the
  * reference does by calling RunOnGPU once per file (src/main.cpp:1952-1985), without the per-launch tail -- a 1080p
  * frame is 2.66 rounds of workgroups, a batch fills every round.  in/out: host arrays of n_frames device pointers.
- * Results are bit-identical to n_frames calls of mid_bilateral (same tile code). */
+ * Results are bit-identical to n_frames calls of mid_bilateral (same tile code).
+ * No aliasing: an `out` buffer must not be any `in` buffer of the same call (all frames are filtered concurrently) nor
+ * appear twice; mid_bilateral likewise rejects in == out.  Violations return MID_ERR_INVALID. */
 int mid_bilateral_batch(mid_ctx *ctx, const mid_bilateral_params *p, const void *const *in /* n_frames device ptrs */,
                         mid_pixel *const *out /* n_frames device ptrs */, int n_frames, void *stream);
 

@@ -151,6 +151,16 @@ def test_animation_mode(tmp_path):
     for i in range(6):
         got = mid.load_image(out / f"output-animation-Animation01_X_{i:04d}.exr")
         assert rel_err(got, ref[i]) < 2e-5, i
+    # --pinned-mb: page-locked memory is budgeted.  0 = every frame pageable; a budget of two frame pairs (frames are
+    # 40x56x16 B = 35,840 B, so 1 MiB holds them all -- use the 0 case and the default to bracket) must give the same files
+    out2 = tmp_path / "o2"
+    out2.mkdir()
+    r = _run([str(d / "Animation01_X_0000.exr"), "--animation", "--temporal-k", "2", "--outdir", str(out2), "--pinned-mb", "0"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "6 frame(s) beyond the page-locked budget" in r.stdout
+    for i in range(6):
+        name = f"output-animation-Animation01_X_{i:04d}.exr"
+        assert np.array_equal(mid.load_image(out2 / name), mid.load_image(out / name)), i
     import torch
     if torch.cuda.device_count() == 1:
         r = _run([str(d / "Animation01_X_0000.exr"), "--animation", "--gpus", "3", "--outdir", str(out)], tmp_path)

@@ -111,3 +111,6 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
     assert t["halo_bytes_recv_per_rank"] == [2 * 1920 * 1080 * 16] * 2 and t["halo_bytes_sent_per_rank"] == [2 * 1920 * 1080 * 16] * 2
     assert len(t["halo_held_ms_per_rank"]) == 2 and t["Mpixel/s_out"] > 0
     assert not [k for k in d["also"] if k.endswith("_error")], d["also"]
+    pg = d["config"]["process_group"]                   # what the ranks ran on, in the line itself
+    assert pg["backend"] == "gloo" and len(pg["devices"]) == 2 and all("gfx950" in n or "MI355" in n or "cuda:0" in n for n in pg["devices"])
+    assert pg["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

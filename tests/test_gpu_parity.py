@@ -431,6 +431,14 @@ def test_bilateral_batch_argument_errors(ctx):
     assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), nul, out, 1, None) == 1
     assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), one, out, 1, None) == 0
     ctx.sync()
+    # ping-pong tables shifted by one slot: out[0] is in[1] -- every frame of a launch runs concurrently, so that is a race
+    d2, o2 = ctx.upload(img), ctx.alloc(8 * 8 * 16)
+    ins = (ctypes.c_void_p * 2)(d.ptr, d2.ptr)
+    assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), ins, (ctypes.c_void_p * 2)(d2.ptr, o2.ptr), 2, None) == 1
+    assert b"also an input" in mid.lib.mid_last_error()
+    assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), ins, (ctypes.c_void_p * 2)(o.ptr, o.ptr), 2, None) == 1   # one buffer twice
+    assert mid.lib.mid_bilateral_batch(ctx.handle, ctypes.byref(p), ins, (ctypes.c_void_p * 2)(o.ptr, o2.ptr), 2, None) == 0
+    ctx.sync()
 
 
 def test_bilateral_batch_chunks_beyond_the_frame_table(ctx):

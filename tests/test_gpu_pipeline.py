@@ -148,38 +148,3 @@ def test_frames_decoded_straight_into_pinned_memory(ctx, tmp_path):
     im = Image()
     assert mid.lib.mid_image_load_pinned(ctx.handle, str(bad).encode(), ctypes.byref(im)) == 5 and not im.data
     assert mid.lib.mid_image_load_pinned(ctx.handle, str(tmp_path / "nope.png").encode(), ctypes.byref(im)) == 5
-
-
-@pytest.mark.parametrize("k,n,chunk", [(2, 24, 3), (0, 17, 4), (1, 9, 1), (3, 40, 5)])
-def test_gated_pipeline_with_many_chunks(ctx, k, n, chunk, monkeypatch):
-    """The gated pipeline (csrc/pipeline.cpp: chunk-sized launches enqueued before their uploads, workgroups gated on
-    per-frame device words, per-frame completion words polled by the host) with SMALL chunks, so that every mechanism
-    (opt-in: MID_PIPE_GATED=1) is exercised many times on a short sequence: input slots recycled (RS = 2*chunk + 2k), output slots recycled two
-    chunks later, launches chained.  Must equal the direct temporal call bit for bit -- float and u8 outputs, whole
-    sequence and a sub-range -- and the event-joined pipeline (MID_PIPE_GATED=0) must give the same bits."""
-    rng = np.random.default_rng(7000 + n)
-    h, w = 44, 83
-    frames = [(synth_hdr(rng, h, w) * 0.25).astype(np.float32) for _ in range(n)]
-    direct = ctx.nlm_temporal(frames, k=k)
-    monkeypatch.setenv("MID_PIPE_CHUNK", str(chunk))
-    monkeypatch.setenv("MID_PIPE_GATED", "1")
-    outs, (wall, kern, copy) = ctx.sequence_nlm(frames, k=k, overlap=True)
-    assert all(np.array_equal(a, b) for a, b in zip(outs, direct)) and wall > 0 and kern > 0 and copy > 0
-    part, _ = ctx.sequence_nlm(frames, k=k, overlap=True, first=2, count=n - 5, pinned=False)
-    assert all(np.array_equal(a, b) for a, b in zip(part, direct[2:n - 3]))
-    u8, _ = ctx.sequence_nlm(frames, k=k, overlap=True, out_u8=True)
-    assert all(np.array_equal(a, oracle.pack_u8(b)) for a, b in zip(u8, direct))
-    monkeypatch.setenv("MID_PIPE_GATED", "0")
-    ev, _ = ctx.sequence_nlm(frames, k=k, overlap=True)
-    assert all(np.array_equal(a, b) for a, b in zip(ev, direct))
-
-
-def test_gated_pipeline_generic_kernel_and_other_windows(ctx, monkeypatch):
-    """Windows without a strip instantiation run the one-thread-per-pixel kernel: gated the same way."""
-    monkeypatch.setenv("MID_PIPE_GATED", "1")
-    rng = np.random.default_rng(7100)
-    frames = [(synth_hdr(rng, 30, 50) * 0.25).astype(np.float32) for _ in range(7)]
-    for search, patch in (((-4, 5), (-2, 2)), ((-7, 8), (-2, 3)), ((-7, 7), (-3, 3))):
-        direct = ctx.nlm_temporal(frames, k=1, search=search, patch=patch)
-        outs, _ = ctx.sequence_nlm(frames, k=1, search=search, patch=patch)
-        assert all(np.array_equal(a, b) for a, b in zip(outs, direct)), (search, patch)

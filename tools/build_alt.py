@@ -1,0 +1,26 @@
+"""Builds an alternative library build/abl/libmi_<name>.so that differs from the shipped one in ONE translation unit
+compiled with extra flags (development A/B only; select it per process with MID_LIB_PATH=build/abl/libmi_<name>.so).
+   python tools/build_alt.py <name> <source under csrc/> [extra hipcc flags ...]
+e.g. python tools/build_alt.py tuning nlm.hip -DMID_NLM_TUNING
+     python tools/build_alt.py bil_align64 bilateral.hip -mllvm -align-loops=64
+The other objects are taken from build/ (run `make` first); nlm.hip keeps the Makefile's max-ILP scheduling flag."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+name, src_rel, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
+ALL = "capi.cpp pointwise.hip bilateral.hip nlm.hip pipeline.cpp codec/png.cpp codec/exr.cpp codec/piz.cpp codec/image_capi.cpp".split()
+assert src_rel in ALL, src_rel
+base = "-x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function".split()
+if src_rel == "nlm.hip":
+    base += ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+d = os.path.join(ROOT, "build", "abl")
+os.makedirs(d, exist_ok=True)
+o = os.path.join(d, f"{name}_{src_rel.replace('/', '_')}.o")
+subprocess.run(["/opt/rocm/bin/hipcc"] + base + extra + ["-I" + os.path.join(ROOT, "include"), "-c",
+                os.path.join(ROOT, "image_denoising_filter_amd/csrc", src_rel), "-o", o], check=True)
+objs = [o if s == src_rel else os.path.join(ROOT, "build", s + ".o") for s in ALL]
+out = os.path.join(d, f"libmi_{name}.so")
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-lz"], check=True)
+print("built", os.path.relpath(out, ROOT), "with", src_rel, " ".join(extra))

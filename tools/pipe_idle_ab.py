@@ -1,7 +1,8 @@
-"""A/B of the frame pipeline's two schedules (16 x 1080p, or 64 with --long; k=0; HDR = RGBA32F in/out, LDR = RGBA8
-in/out).  Each line is a fresh process: the gated pipeline (MID_PIPE_GATED=1), the event-joined default, and -- on the
-"plain" line -- ONE batched launch over the same frames resident in HBM, back to back and after an idle GPU (the clock
-ramp that separates the 16-frame pipeline figures from the kernel's batched rate)."""
+"""The frame pipeline against one batched launch (16 x 1080p, or 64 with --long; k=0; HDR = RGBA32F in/out, LDR = RGBA8
+in/out).  Each line is a fresh process: the event-joined pipeline, and -- on the "plain" line -- ONE batched launch over
+the same frames resident in HBM, back to back and after an idle GPU (the clock ramp that separates the 16-frame pipeline
+figures from the kernel's batched rate).  (Round 2 also ran the gated chunk-launch schedule here; it measured no gain and
+was removed from the library in round 3 -- last present at commit 06500d5.)"""
 import os, sys, subprocess
 code = r'''
 import os, sys
@@ -40,7 +41,7 @@ for name, fr, u8 in (("hdr", hdr, False), ("ldr", ldr, True)):
             mid.lib.mid_timer_tock(tm, None); mid.lib.mid_timer_ms(tm, ctypes.byref(ms))
             print(f"{'plain launch, after idle':28s} {name}: {ms.value:6.2f} ms for one {n}-frame launch after {idle*1e3:.0f} ms of idle GPU", flush=True)
 '''
-runs = [("gated", {"MID_PIPE_GATED": "1"}), ("event-joined", {"MID_PIPE_GATED": "0"}), ("plain", {"MID_PIPE_GATED": "0"})]
+runs = [("event-joined", {}), ("plain", {})]
 if "--long" in sys.argv:
     os.environ["PROBE_FRAMES"] = "64"
 for label, env in runs:

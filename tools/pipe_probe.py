@@ -12,9 +12,6 @@ ctx.sequence_nlm(frames[:2], k=0, **mid.NLM_BENCH)
 for k in (0, 2):
     for ov in (True, False):
         outs, (wall, kern, copy) = ctx.sequence_nlm(frames, k=k, overlap=ov, **mid.NLM_BENCH)
-        print(f"batch={os.environ.get('MID_PIPE_BATCH','auto')} k={k} overlap={ov}: wall {wall:.2f} ms kernel {kern:.2f} copy {copy:.2f} -> {n*1920*1080/wall/1e3:.0f} Mpx/s", flush=True)
+        print(f"k={k} overlap={ov}: wall {wall:.2f} ms kernel {kern:.2f} copy {copy:.2f} -> {n*1920*1080/wall/1e3:.0f} Mpx/s", flush=True)
 '''
-for b in sys.argv[1:]:
-    env = dict(os.environ)
-    if b != "auto": env["MID_PIPE_BATCH"] = b
-    subprocess.run([sys.executable, "-c", code], env=env, check=True)
+subprocess.run([sys.executable, "-c", code], check=True)   # (a fresh process: cold pinned-memory pools like a real caller)

@@ -1,5 +1,4 @@
-"""Pipeline throughput for RGBA32F and for RGBA8 in / RGBA8 out (16 x 1080p, k=0).  Arguments are labels only;
-the library pipelines over two kernel streams (1/2/3/4 were compared with a development switch: 2385/2575/1892/1652)."""
+"""Pipeline throughput for RGBA32F and for RGBA8 in / RGBA8 out (16 x 1080p, k=0).  The library pipelines over two kernel streams (1/2/3/4 were compared with a development switch: 2385/2575/1892/1652)."""
 import os, sys, subprocess
 code = r'''
 import os, sys
@@ -15,7 +14,6 @@ for name, fr, u8 in (("hdr", hdr, False), ("ldr", ldr, True)):
     ctx.sequence_nlm(fr[:2], k=0, out_u8=u8, **mid.NLM_BENCH)
     for rep in range(2):
         outs, (wall, kern, copy) = ctx.sequence_nlm(fr, k=0, overlap=True, out_u8=u8, **mid.NLM_BENCH)
-    print(f"streams={os.environ.get('MID_PIPE_STREAMS','2')} {name}: wall {wall:.2f} ms kernel-sum {kern:.2f} copy-sum {copy:.2f} -> {n*1920*1080/wall/1e3:.0f} Mpx/s", flush=True)
+    print(f"{name}: wall {wall:.2f} ms kernel-sum {kern:.2f} copy-sum {copy:.2f} -> {n*1920*1080/wall/1e3:.0f} Mpx/s", flush=True)
 '''
-for b in sys.argv[1:]:
-    subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MID_PIPE_STREAMS=b), check=True)
+subprocess.run([sys.executable, "-c", code], check=True)

@@ -507,12 +507,28 @@ def main():
             return tm.ms()[0] / n / 1e3
 
         def extra_bilateral():
-            for name, layout in (("bilateral_r8_linear", mid.LAYOUT_LINEAR), ("bilateral_r8_texture", mid.LAYOUT_TEXTURE)):
-                s = time_gpu(lambda: ctx.bilateral_dev(fptr[0], optr[0], W, H, 8, 2.0, 0.2, layout, mid.FMT_RGBA32F, stream))
-                also[name] = {"Mpixel/s": round(NPIX / 1e6 / s, 1), "ms": round(s * 1e3, 4),
+            # The two layouts run the same inner loop (identical opcode stream; only the tile fill differs).  Timed one after
+            # the other, 10 launches each, whichever came SECOND read 3-6 % slower (rounds 1-2: 0.181 vs 0.193 ms; the
+            # profiler's launch mix, which runs texture first, and an interleaved A/B both show them equal):
+            # 2 ms of 0.18 ms launches between host-side gaps sit on the GPU's clock ramp.  So: warm both, then alternate
+            # them (order flipped every repetition), 20 launches per timing, and report each layout's median.
+            layouts = (("bilateral_r8_linear", mid.LAYOUT_LINEAR), ("bilateral_r8_texture", mid.LAYOUT_TEXTURE))
+            fns = {name: (lambda lay=layout: ctx.bilateral_dev(fptr[0], optr[0], W, H, 8, 2.0, 0.2, lay, mid.FMT_RGBA32F, stream))
+                   for name, layout in layouts}
+            for name, _ in layouts:
+                time_gpu(fns[name], 20)
+            samples = {name: [] for name, _ in layouts}
+            for rep in range(7):
+                for name, _ in (layouts if rep % 2 == 0 else layouts[::-1]):
+                    samples[name].append(time_gpu(fns[name], 20))
+            for name, _ in layouts:
+                s = sorted(samples[name])[len(samples[name]) // 2]
+                also[name] = {"Mpixel/s": round(NPIX / 1e6 / s, 1), "ms": round(s * 1e3, 4), "ms_min": round(min(samples[name]) * 1e3, 4),
                               "valu_frac": round(BIL_FLOP_PER_PX * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
                               "hbm_GBs": round(BIL_BYTES_PER_PX * NPIX / s / 1e9, 1),
-                              "hbm_frac": round(BIL_BYTES_PER_PX * NPIX / s / 1e9 / PEAK_HBM_GBS, 5)}
+                              "hbm_frac": round(BIL_BYTES_PER_PX * NPIX / s / 1e9 / PEAK_HBM_GBS, 5),
+                              "timing": "median of 7 interleaved timings of 20 launches"}
+            also["bilateral_r8_texture_over_linear"] = round(also["bilateral_r8_texture"]["ms"] / also["bilateral_r8_linear"]["ms"], 4)
 
         guarded("bilateral", extra_bilateral)
 
@@ -648,15 +664,19 @@ def main():
                 hf = [f.cpu().numpy() for f in frames]
                 lf8 = [np.clip(f * 64.0, 0, 255).astype(np.uint8) for f in hf]
                 lf = [lf8[i % F] for i in range(SEQ_FRAMES)]
-                for _rep in range(2):       # the second pass is reported: the first one also pays for first-use of the larger buffers
-                    _, (wall8, kern8, copy8) = ctx.sequence_nlm(lf, k=0, overlap=True, search=SEARCH, patch=PATCH, out_u8=True)
-                also["pipeline_pcie_inclusive_ldr_64"] = {"Mpixel/s_overlap": round(len(lf) * NPIX / 1e3 / wall8, 1), "frames": len(lf),
-                                                          "kernel_ms": round(kern8, 3), "copy_ms": round(copy8, 3)}
+                def passes(fr, **kw):
+                    # pass 0 also pays for first use of the larger buffers and is dropped; of the next four the MEDIAN is
+                    # reported, with the spread beside it -- this figure moved 2480-3100 between boxes and runs in rounds
+                    # 2-3 at an unchanged kernel rate, so one pass is not a measurement
+                    rows = [ctx.sequence_nlm(fr, k=0, overlap=True, search=SEARCH, patch=PATCH, **kw)[1] for _ in range(5)][1:]
+                    rows.sort(key=lambda r: r[0])
+                    wall, kern, copy = rows[len(rows) // 2]
+                    return {"Mpixel/s_overlap": round(len(fr) * NPIX / 1e3 / wall, 1), "frames": len(fr),
+                            "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3),
+                            "Mpixel/s_min_max_of_4_passes": [round(len(fr) * NPIX / 1e3 / rows[-1][0], 1), round(len(fr) * NPIX / 1e3 / rows[0][0], 1)]}
+                also["pipeline_pcie_inclusive_ldr_64"] = passes(lf, out_u8=True)
                 hf = [hf[i % F] for i in range(SEQ_FRAMES)]
-                for _rep in range(2):
-                    _, (wall, kern, copy) = ctx.sequence_nlm(hf, k=0, overlap=True, search=SEARCH, patch=PATCH)
-                also["pipeline_pcie_inclusive_64"] = {"Mpixel/s_overlap": round(len(hf) * NPIX / 1e3 / wall, 1), "frames": len(hf),
-                                                      "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3)}
+                also["pipeline_pcie_inclusive_64"] = passes(hf)
 
         guarded("pipeline_long", extra_pipeline_long)
 

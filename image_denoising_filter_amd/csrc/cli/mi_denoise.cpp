@@ -321,7 +321,7 @@ public:
         for (auto &f : frameNames) {
             mid_image img{};
             // inputs and outputs share the budget frame by frame: input i is pinned only if output i can be as well
-            bool pinned = pinned_bytes + 2 * frame_bytes_guess <= pinned_budget;
+            bool pinned = pinned_budget > 0 && pinned_bytes + 2 * frame_bytes_guess <= pinned_budget;   // (the first frame's size is not known yet: any non-zero budget admits it)
             if (pinned && mid_image_load_pinned(io, f.c_str(), &img)) pinned = false;      // no page-locked memory left (or a bad file: the pageable load below reports that)
             if (!pinned && mid_image_load(f.c_str(), &img)) throw std::runtime_error(mid_last_error());
             pin.frames.push_back(img);

@@ -21,6 +21,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH2 > $O
 # the same counters for the other kernels of the path (bilateral variants, temporal NLM, streaming passes)
 MIX="python3 $R/tools/profile_kernels.py 3"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_mix_sq1 -- $MIX > $OUT/pmc_mix_sq1.log 2>&1 || { echo "pmc_mix_sq1 failed"; tail -5 $OUT/pmc_mix_sq1.log; exit 1; }
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mix_sq2 -- $MIX > $OUT/pmc_mix_sq2.log 2>&1 || { echo "pmc_mix_sq2 failed"; tail -5 $OUT/pmc_mix_sq2.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_mix -- $MIX > $OUT/trace_mix.log 2>&1 || { echo "trace_mix failed"; tail -5 $OUT/trace_mix.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_mix_fetch -- $MIX > $OUT/pmc_mix_fetch.log 2>&1 || { echo "pmc_mix_fetch failed"; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_mix_write -- $MIX > $OUT/pmc_mix_write.log 2>&1 || { echo "pmc_mix_write failed"; exit 1; }
 find $OUT -name "*.csv" | head -30

@@ -3,7 +3,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := image_denoising_filter_amd/csrc
 LIB     := image_denoising_filter_amd/libmi_denoise.so
-SRCS    := $(CSRC)/capi.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/pipeline.cpp \
+SRCS    := $(CSRC)/capi.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/pipeline.cpp $(CSRC)/sharded.cpp \
            $(CSRC)/codec/png.cpp $(CSRC)/codec/exr.cpp $(CSRC)/codec/piz.cpp $(CSRC)/codec/image_capi.cpp
 OBJS    := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 HIPFLAGS := -x hip --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Iinclude
@@ -17,7 +17,7 @@ $(CLI): $(CSRC)/cli/mi_denoise.cpp include/mi_denoise.h $(LIB)
 	g++ -std=c++17 -O2 -fopenmp -Wall -o $@ $(CSRC)/cli/mi_denoise.cpp -Limage_denoising_filter_amd -lmi_denoise -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -lz -ldl
 
 # per-file extras: the NLM kernels gain 2-6 % from LLVM's max-ILP scheduling strategy (A/B on MI355X: 3074 vs 3011
 # Mpixel/s batched, 2882 vs 2710 single frame); the bilateral kernels lose 8 % with it, so it stays off there.

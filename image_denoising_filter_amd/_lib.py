@@ -91,6 +91,20 @@ _SIGNATURES = {
                                                  ctypes.POINTER(ctypes.c_float)]),
     "mid_nlm_multiframe": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), _P, c_void_pp, ctypes.c_int, _P, ctypes.c_int,
                                           ctypes.POINTER(ctypes.c_float)]),
+    "mid_shard_block": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "mid_shard_halo_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "mid_shard_launch_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "mid_comm_unique_id": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
+    "mid_comm_create": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.c_int, c_void_pp]),
+    "mid_comm_create_all": (ctypes.c_int, [c_void_pp, ctypes.c_int, c_void_pp]),
+    "mid_comm_destroy": (ctypes.c_int, [_P]),
+    "mid_comm_rank": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "mid_comm_loopback": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
+    "mid_nlm_temporal_sharded": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), c_void_pp, ctypes.c_int, ctypes.c_int, c_void_pp, _P]),
+    "mid_comm_last_exchange": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_float)]),
     "mid_image_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Image)]),
     "mid_image_free": (None, [ctypes.POINTER(Image)]),
     "mid_image_load_pinned": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(Image)]),

@@ -341,3 +341,80 @@ class Context:
                     lib.mid_free_host(self.handle, p)
             for q in hout:
                 lib.mid_free_host(self.handle, q)
+
+
+# ---- an animation sharded over GPUs: the C++ RCCL path (csrc/sharded.cpp) ----------------------------------------
+COMM_ID_BYTES = 128
+
+
+def shard_block(n_frames, world, rank):
+    """(start, count) of rank's contiguous frame block (mid_shard_block) -- host only."""
+    a, b = ctypes.c_int(), ctypes.c_int()
+    _check(lib.mid_shard_block(n_frames, world, rank, ctypes.byref(a), ctypes.byref(b)), "mid_shard_block")
+    return a.value, b.value
+
+
+def shard_halo_plan(n_frames, world, k, rank):
+    """(recv, send): lists of (peer rank, global frame id) in the order csrc/sharded.cpp issues them -- host only."""
+    cap = 2 * max(k, 1) * max(world, 1) + 4 * max(k, 1) + 8
+    arr = [(ctypes.c_int * cap)() for _ in range(4)]
+    nr, ns = ctypes.c_int(), ctypes.c_int()
+    _check(lib.mid_shard_halo_plan(n_frames, world, k, rank, cap, arr[0], arr[1], ctypes.byref(nr), arr[2], arr[3], ctypes.byref(ns)),
+           "mid_shard_halo_plan")
+    return ([(arr[0][i], arr[1][i]) for i in range(nr.value)], [(arr[2][i], arr[3][i]) for i in range(ns.value)])
+
+
+def shard_launch_plan(n_frames, world, k, rank):
+    """[(phase, w_lo, w_hi, first, count, out_offset)] like sharding.block_launch_plan, from the C++ side -- host only."""
+    rows = (ctypes.c_int * (6 * 8))()
+    n = ctypes.c_int()
+    _check(lib.mid_shard_launch_plan(n_frames, world, k, rank, 8, rows, ctypes.byref(n)), "mid_shard_launch_plan")
+    return [("interior" if rows[6 * i] else "boundary",) + tuple(rows[6 * i + 1:6 * i + 6]) for i in range(n.value)]
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C-ABI: 128 bytes rank 0 hands to the other ranks (file, MPI, torch.distributed)."""
+    buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+    _check(lib.mid_comm_unique_id(buf), "mid_comm_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    """One rank of an RCCL communicator bound to a Context (mid_comm_create): one process per GPU."""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        h = ctypes.c_void_p()
+        idb = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _check(lib.mid_comm_create(ctx.handle, idb, rank, world, ctypes.byref(h)), "mid_comm_create")
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib.mid_comm_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def loopback(self, src_ptr, dst_ptr, nbytes, stream=None):
+        _check(lib.mid_comm_loopback(self.handle, src_ptr, dst_ptr, nbytes, stream), "mid_comm_loopback")
+
+    def nlm_temporal_sharded_dev(self, block_ptrs, out_ptrs, w, h, n_frames, k, hparam, search, patch, fmt, stream=None):
+        """This rank's block (device pointers, in order) -> its outputs; halo over RCCL, interior launches meanwhile."""
+        _, count = shard_block(n_frames, self.world, self.rank)
+        if len(block_ptrs) != count or len(out_ptrs) != count:
+            raise ValueError(f"rank {self.rank} owns {count} frames, got {len(block_ptrs)} inputs / {len(out_ptrs)} outputs")
+        p = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], fmt)
+        fr = (ctypes.c_void_p * max(count, 1))(*block_ptrs)
+        ou = (ctypes.c_void_p * max(count, 1))(*out_ptrs)
+        _check(lib.mid_nlm_temporal_sharded(self.handle, ctypes.byref(p), fr, n_frames, k, ou, stream), "mid_nlm_temporal_sharded")
+
+    def last_exchange(self):
+        """(bytes received, bytes sent, exchange ms) of the last sharded call; waits for that exchange."""
+        a, b, ms = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_float()
+        _check(lib.mid_comm_last_exchange(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(ms)), "mid_comm_last_exchange")
+        return a.value, b.value, ms.value

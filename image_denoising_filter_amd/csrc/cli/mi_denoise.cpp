@@ -57,6 +57,7 @@ struct Options {
     std::string modes = "all";      // comma list of: bilateral,layers,linear,nlm,multiframe,overlap
     bool animation = false;         // new capability: temporal NLM of EVERY frame of the sequence
     int gpus = 1;                   // animation mode: frame blocks over this many devices
+    bool halo_rccl = false;         // animation mode: blocks resident in HBM, halo frames GPU to GPU over RCCL (mid_nlm_temporal_sharded)
     long pinned_mb = 16384;         // animation mode: at most this much page-locked host memory (inputs + outputs); the rest is pageable
 };
 
@@ -274,9 +275,10 @@ public:
     // Animation mode (BASELINE config 5; not in the reference, which filters one target per run): every
     // sibling frame of the target is denoised with temporal NLM over frames t-k..t+k.  Frames are split
     // into contiguous blocks, one per device; each device streams its block plus k halo frames on either
-    // side through the 3-stream pipeline (mid_sequence_nlm_range).  All frames sit in host memory here, so
-    // the halo needs no device-to-device exchange (bench.py / sharding.py cover the RCCL case, where
-    // frames are GPU-resident).  Outputs: output-animation-<frame file name>.
+    // side through the 3-stream pipeline (mid_sequence_nlm_range): all frames sit in host memory, so by default
+    // the halo is simply uploaded twice and needs no device-to-device exchange.  With --halo rccl every block is
+    // uploaded once, stays resident in its GPU's HBM, and the halo frames travel GPU to GPU over RCCL/xGMI
+    // (mid_nlm_temporal_sharded, csrc/sharded.cpp).  Outputs: output-animation-<frame file name>.
     void RunAnimation()
     {
         std::vector<std::string> frameNames, layerNames;
@@ -386,11 +388,52 @@ public:
         std::vector<std::string> errors(G);
         std::vector<float> kern(G, 0.f), copy(G, 0.f);
         std::vector<std::thread> workers;
+        // --halo rccl: one communicator rank per device (one process, ncclCommInitAll); created before the clock starts,
+        // like the contexts
+        std::vector<mid_comm *> comms(G, nullptr);
+        struct CommGuard { std::vector<mid_comm *> &v; ~CommGuard() { for (auto c : v) if (c) (void)mid_comm_destroy(c); } } cguard{comms};
+        if (opt.halo_rccl) MID_CHECK(mid_comm_create_all(ctxs.data(), G, comms.data()));
         const auto t0 = std::chrono::steady_clock::now();
         for (int g = 0; g < G; ++g)
             workers.emplace_back([&, g] {
                 try {
                     const int q = n / G, r = n % G, start = g * q + std::min(g, r), count = q + (g < r ? 1 : 0);
+                    if (opt.halo_rccl) {
+                        // GPU-resident variant: the block is uploaded once and stays in HBM; the k frames on either side come
+                        // from the neighbouring devices over xGMI (ncclSend/ncclRecv, one group) while the interior frames are
+                        // being filtered; no frame is uploaded twice.  Every rank calls in, also one that owns no frame.
+                        mid_ctx *ctx = ctxs[g];
+                        struct Dev { mid_ctx *c; std::vector<void *> p; ~Dev() { for (auto q : p) if (q) (void)mid_free(c, q); } } din{ctx, {}}, dout{ctx, {}};
+                        mid_timer *tk = nullptr, *tc = nullptr;
+                        MID_CHECK(mid_timer_create(ctx, &tk));
+                        MID_CHECK(mid_timer_create(ctx, &tc));
+                        struct TG { mid_timer *a, *b; ~TG() { (void)mid_timer_destroy(a); (void)mid_timer_destroy(b); } } tg{tk, tc};
+                        MID_CHECK(mid_timer_tick(tc, nullptr));
+                        for (int i = 0; i < count; ++i) {
+                            void *d = nullptr;
+                            MID_CHECK(mid_alloc(ctx, in_bytes, &d)); din.p.push_back(d);
+                            MID_CHECK(mid_memcpy_h2d(ctx, d, in[start + i], in_bytes, nullptr));
+                            MID_CHECK(mid_alloc(ctx, (size_t)w * h * 16, &d)); dout.p.push_back(d);
+                        }
+                        MID_CHECK(mid_timer_tock(tc, nullptr));
+                        MID_CHECK(mid_timer_tick(tk, nullptr));
+                        MID_CHECK(mid_nlm_temporal_sharded(comms[g], &p, din.p.data(), n, k, (mid_pixel *const *)dout.p.data(), nullptr));
+                        MID_CHECK(mid_timer_tock(tk, nullptr));
+                        void *u8 = nullptr;
+                        if (!hdr && count) { MID_CHECK(mid_alloc(ctx, out_bytes, &u8)); din.p.push_back(u8); }
+                        for (int i = 0; i < count; ++i) {
+                            if (hdr) MID_CHECK(mid_memcpy_d2h(ctx, pin.outs[start + i], dout.p[i], out_bytes, nullptr));
+                            else {   // GetImageFromGPU's u8 conversion (:97-103) on the device, then a quarter of the bytes come back
+                                MID_CHECK(mid_pack_u8(ctx, (const float *)dout.p[i], (size_t)w * h * 4, (uint8_t *)u8, nullptr));
+                                MID_CHECK(mid_memcpy_d2h(ctx, pin.outs[start + i], u8, out_bytes, nullptr));
+                            }
+                        }
+                        MID_CHECK(mid_stream_sync(ctx, nullptr));
+                        float ms = 0.f;
+                        MID_CHECK(mid_timer_ms(tk, &ms)); kern[g] = ms;
+                        MID_CHECK(mid_timer_ms(tc, &ms)); copy[g] = ms;
+                        return;
+                    }
                     if (count == 0) return;
                     mid_ctx *ctx = ctxs[g];
                     float t[3] = {0, 0, 0};
@@ -481,6 +524,9 @@ static void usage()
         "  --temporal-k K            multiframe: frames t-K..t+K of the sorted sequence instead of the reference's list\n"
         "  --animation               denoise EVERY sibling frame with temporal NLM (window +-K, default 2) instead of the mode list\n"
         "  --gpus N                  animation mode: split the sequence into N frame blocks, one per device\n"
+        "  --halo host|rccl          animation mode with --gpus N: 'host' (default) streams every block plus its K halo frames from host\n"
+        "                            memory through the overlapped pipeline; 'rccl' keeps each block resident in its GPU's HBM and\n"
+        "                            exchanges the halo frames GPU to GPU over RCCL/xGMI\n"
         "  --pinned-mb M             animation mode: page-lock at most M MiB of host memory for frames in and out (default 16384);\n"
         "                            frames beyond that, or whose page-locked allocation fails, use pageable memory\n"
         "  --cpu-radius R --cpu-sigma-s S --cpu-sigma-c C   CPU path (default 10 10.0 0.2)\n"
@@ -513,6 +559,7 @@ int main(int argc, char **argv)
         else if (a == "--animation") opt.animation = true;
         else if (a == "--gpus") opt.gpus = atoi(next());
         else if (a == "--pinned-mb") opt.pinned_mb = atol(next());
+        else if (a == "--halo") { const std::string v = next(); if (v == "rccl") opt.halo_rccl = true; else if (v != "host") { usage(); return EXIT_FAILURE; } }
         else if (a == "--cpu-radius") opt.cpu_radius = atoi(next());
         else if (a == "--cpu-sigma-s") opt.cpu_sigma_s = (float)atof(next());
         else if (a == "--cpu-sigma-c") opt.cpu_sigma_c = (float)atof(next());

@@ -1,0 +1,389 @@
+// sharded.cpp -- frame-block sharding of an animation over GPUs, with the temporal-NLM halo exchanged GPU to GPU over
+// RCCL (xGMI), from C++ (BASELINE configs[4]).
+//
+// The reference is single-device (deviceId{0}, src/main.cpp:1321) and filters ONE target per run against its
+// neighbour frames (loop src/main.cpp:1577-1606); here every frame t of an n-frame sequence is an output, accumulated
+// over the explicit window t-k..t+k (clipped at the sequence ends).  One rank per GPU owns a contiguous block of frames,
+// resident in its HBM.  The only data another rank holds that a rank needs are the k frames on either side of its block:
+// ONE exchange step -- ncclSend/ncclRecv inside one group, point to point with the neighbouring rank(s); no all-reduce,
+// no all-gather -- after which the rank filters its block with the same kernels as a single GPU does.
+//
+//   stream (caller's)   : [e0] interior outputs ................ [wait e1] boundary outputs
+//   exchange stream     : [wait e0] group{recv halo, send edges} [e1]
+//
+// Interior outputs (windows inside the rank's own block) are launched while the halo is in flight; the <= 2k boundary
+// outputs wait for it.  The launch plan (which outputs are interior, which frame table each launch sees) is the one
+// image_denoising_filter_amd/sharding.py::block_launch_plan states and the gloo tests pin; mid_shard_* expose it as pure
+// host functions so that the C++ and Python statements are tested against each other on the CPU.
+//
+// RCCL is bound at RUN time (dlopen of librccl.so.1 on the first mid_comm_* call): the library itself has no link-time
+// dependency on it, single-GPU users never load it, and inside a PyTorch process the dlopen resolves to the copy torch
+// has already mapped (same SONAME), so there is one RCCL per process.
+#include "common.hpp"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string>
+#include <vector>
+
+using namespace mid;
+
+namespace {
+
+struct Rccl {
+    void *so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (x.so) break;
+        }
+        if (!x.so) { x.why = std::string("cannot load librccl.so.1: ") + (dlerror() ? dlerror() : "?"); return x; }
+        auto sym = [&](const char *n) { void *p = dlsym(x.so, n); if (!p && x.why.empty()) x.why = std::string("librccl lacks ") + n; return p; };
+        x.GetUniqueId = (decltype(x.GetUniqueId))sym("ncclGetUniqueId");
+        x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
+        x.CommInitAll = (decltype(x.CommInitAll))sym("ncclCommInitAll");
+        x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy");
+        x.GroupStart = (decltype(x.GroupStart))sym("ncclGroupStart");
+        x.GroupEnd = (decltype(x.GroupEnd))sym("ncclGroupEnd");
+        x.Send = (decltype(x.Send))sym("ncclSend");
+        x.Recv = (decltype(x.Recv))sym("ncclRecv");
+        x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
+        return x;
+    }();
+    return r;
+}
+
+#define MID_NCCL(call)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t r__ = (call);                                                                         \
+        if (r__ != ncclSuccess)                                                                            \
+            return set_error(MID_ERR_HIP, "%s failed: %s (%s:%d)", #call, rccl().GetErrorString(r__), __FILE__, __LINE__); \
+    } while (0)
+
+int need_rccl()
+{
+    Rccl &r = rccl();
+    if (!r.so || !r.why.empty()) return set_error(MID_ERR_UNSUPPORTED, "RCCL is not available: %s", r.why.c_str());
+    return MID_OK;
+}
+
+// ---- pure host logic (also exported: mid_shard_block / mid_shard_halo_plan / mid_shard_launch_plan) ----
+void block_of(int n, int world, int rank, int &start, int &count)
+{
+    const int q = n / world, r = n % world;                 // the first n % world ranks get one extra frame
+    start = rank * q + (rank < r ? rank : r);
+    count = q + (rank < r ? 1 : 0);
+}
+
+int owner_of(int n, int world, int f)
+{
+    const int q = n / world, r = n % world;
+    const int big = r * (q + 1);
+    if (f < big) return f / (q + 1);
+    return q ? r + (f - big) / q : world - 1;
+}
+
+// frames rank `r` needs but does not own, ascending
+void needs_of(int n, int world, int k, int r, std::vector<int> &out)
+{
+    out.clear();
+    int s, c;
+    block_of(n, world, r, s, c);
+    if (c == 0 || k == 0) return;
+    const int lo = s - k < 0 ? 0 : s - k, hi = s + c - 1 + k > n - 1 ? n - 1 : s + c - 1 + k;
+    for (int f = lo; f <= hi; ++f)
+        if (f < s || f >= s + c) out.push_back(f);
+}
+
+struct Xfer { int peer, frame; };
+
+// recv: this rank's needs, ascending frame (the peer is the owner).  send: for every OTHER rank in ascending rank order,
+// the frames it needs that this rank owns, ascending.  Between any two ranks a and b the frames a sends to b are, in
+// order, exactly the frames b receives from a: both sides enumerate "needs(b) owned by a" ascending -- RCCL matches the
+// sends and receives of a pair in issue order.
+void halo_plan(int n, int world, int k, int rank, std::vector<Xfer> &recv, std::vector<Xfer> &send)
+{
+    recv.clear(); send.clear();
+    std::vector<int> nd;
+    needs_of(n, world, k, rank, nd);
+    for (int f : nd) recv.push_back({owner_of(n, world, f), f});
+    int s, c;
+    block_of(n, world, rank, s, c);
+    if (c == 0) return;
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) continue;
+        needs_of(n, world, k, r, nd);
+        for (int f : nd)
+            if (f >= s && f < s + c) send.push_back({r, f});
+    }
+}
+
+struct Launch { int interior, w_lo, w_hi, first, count, off; };
+
+// sharding.py::block_launch_plan, statement for statement
+void launch_plan(int n, int world, int k, int rank, std::vector<Launch> &plan)
+{
+    plan.clear();
+    int start, count;
+    block_of(n, world, rank, start, count);
+    if (count == 0) return;
+    const int lo_int = start == 0 ? start : start + k;
+    const int hi_int = start + count == n ? start + count : start + count - k;   // exclusive
+    if (hi_int > lo_int) {
+        const int w_lo = start > lo_int - k ? start : lo_int - k;
+        const int w_hi = start + count - 1 < hi_int - 1 + k ? start + count - 1 : hi_int - 1 + k;
+        plan.push_back({1, w_lo, w_hi, lo_int - w_lo, hi_int - lo_int, lo_int - start});
+    }
+    const int edges[2][2] = {{start, lo_int < start + count ? lo_int : start + count},
+                             {hi_int > lo_int ? hi_int : lo_int, start + count}};
+    for (auto &e : edges) {
+        const int a = e[0], b = e[1];
+        if (b > a) {
+            const int w_lo = a - k < 0 ? 0 : a - k, w_hi = b - 1 + k > n - 1 ? n - 1 : b - 1 + k;
+            plan.push_back({0, w_lo, w_hi, a - w_lo, b - a, a - start});
+        }
+    }
+}
+
+}  // namespace
+
+struct mid_comm {
+    mid_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t xs = nullptr;               // exchange stream
+    hipEvent_t e0 = nullptr, e1 = nullptr, x0 = nullptr;
+    std::vector<void *> halo;               // device buffers for received frames, grown on demand
+    size_t halo_bytes = 0;                  // size of each
+    size_t last_recv = 0, last_sent = 0;
+    bool timed = false;
+};
+
+static int comm_finish_create(mid_comm *c)
+{
+    MID_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+    MID_HIP(hipEventCreateWithFlags(&c->e0, hipEventDisableTiming));
+    MID_HIP(hipEventCreate(&c->e1));
+    MID_HIP(hipEventCreate(&c->x0));
+    return MID_OK;
+}
+
+extern "C" int mid_shard_block(int n_frames, int world, int rank, int *start, int *count)
+{
+    MID_REQUIRE(n_frames >= 0 && world >= 1 && rank >= 0 && rank < world && start && count, "shard_block: bad argument");
+    block_of(n_frames, world, rank, *start, *count);
+    return MID_OK;
+}
+
+extern "C" int mid_shard_halo_plan(int n_frames, int world, int k, int rank, int cap,
+                                   int *recv_peer, int *recv_frame, int *n_recv,
+                                   int *send_peer, int *send_frame, int *n_send)
+{
+    MID_REQUIRE(n_frames >= 0 && world >= 1 && rank >= 0 && rank < world && k >= 0 && n_recv && n_send, "shard_halo_plan: bad argument");
+    std::vector<Xfer> rv, sd;
+    if (world > 1) halo_plan(n_frames, world, k, rank, rv, sd);
+    *n_recv = (int)rv.size(); *n_send = (int)sd.size();
+    MID_REQUIRE((int)rv.size() <= cap && (int)sd.size() <= cap, "shard_halo_plan: %zu receives / %zu sends do not fit cap %d", rv.size(), sd.size(), cap);
+    for (size_t i = 0; i < rv.size(); ++i) { if (recv_peer) recv_peer[i] = rv[i].peer; if (recv_frame) recv_frame[i] = rv[i].frame; }
+    for (size_t i = 0; i < sd.size(); ++i) { if (send_peer) send_peer[i] = sd[i].peer; if (send_frame) send_frame[i] = sd[i].frame; }
+    return MID_OK;
+}
+
+extern "C" int mid_shard_launch_plan(int n_frames, int world, int k, int rank, int cap, int *rows /* cap x 6 */, int *n_rows)
+{
+    MID_REQUIRE(n_frames >= 0 && world >= 1 && rank >= 0 && rank < world && k >= 0 && rows && n_rows, "shard_launch_plan: bad argument");
+    std::vector<Launch> pl;
+    launch_plan(n_frames, world, k, rank, pl);
+    *n_rows = (int)pl.size();
+    MID_REQUIRE((int)pl.size() <= cap, "shard_launch_plan: %zu rows do not fit cap %d", pl.size(), cap);
+    for (size_t i = 0; i < pl.size(); ++i) {
+        int *r = rows + 6 * i;
+        r[0] = pl[i].interior; r[1] = pl[i].w_lo; r[2] = pl[i].w_hi; r[3] = pl[i].first; r[4] = pl[i].count; r[5] = pl[i].off;
+    }
+    return MID_OK;
+}
+
+extern "C" int mid_comm_unique_id(uint8_t id[MID_COMM_ID_BYTES])
+{
+    static_assert(MID_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    MID_REQUIRE(id != nullptr, "comm_unique_id: id is NULL");
+    if (int rc = need_rccl()) return rc;
+    ncclUniqueId u;
+    MID_NCCL(rccl().GetUniqueId(&u));
+    memcpy(id, u.internal, MID_COMM_ID_BYTES);
+    return MID_OK;
+}
+
+extern "C" int mid_comm_create(mid_ctx *ctx, const uint8_t id[MID_COMM_ID_BYTES], int rank, int world, mid_comm **out)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(out && id && world >= 1 && rank >= 0 && rank < world, "comm_create: bad argument (rank %d of %d)", rank, world);
+    *out = nullptr;
+    if (int rc = need_rccl()) return rc;
+    ncclUniqueId u;
+    memcpy(u.internal, id, MID_COMM_ID_BYTES);
+    mid_comm *c = new mid_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) { delete c; return set_error(MID_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl().GetErrorString(r)); }
+    if (int rc = comm_finish_create(c)) { (void)mid_comm_destroy(c); return rc; }
+    *out = c;
+    return MID_OK;
+}
+
+extern "C" int mid_comm_create_all(mid_ctx *const *ctxs, int world, mid_comm **out)
+{
+    MID_REQUIRE(ctxs && out && world >= 1 && world <= 64, "comm_create_all: bad argument");
+    for (int i = 0; i < world; ++i) { MID_REQUIRE(ctxs[i], "comm_create_all: context %d is NULL", i); out[i] = nullptr; }
+    if (int rc = need_rccl()) return rc;
+    std::vector<int> devs(world);
+    std::vector<ncclComm_t> comms(world, nullptr);
+    for (int i = 0; i < world; ++i) devs[i] = ctxs[i]->device;
+    MID_NCCL(rccl().CommInitAll(comms.data(), world, devs.data()));
+    for (int i = 0; i < world; ++i) {
+        mid_comm *c = new mid_comm();
+        c->ctx = ctxs[i]; c->rank = i; c->world = world; c->comm = comms[i];
+        out[i] = c;
+    }
+    for (int i = 0; i < world; ++i) {
+        Bind b(ctxs[i], nullptr);
+        int rc = b.rc ? b.rc : comm_finish_create(out[i]);
+        if (rc) { for (int j = 0; j < world; ++j) { (void)mid_comm_destroy(out[j]); out[j] = nullptr; } return rc; }
+    }
+    return MID_OK;
+}
+
+extern "C" int mid_comm_destroy(mid_comm *c)
+{
+    if (!c) return MID_OK;
+    (void)hipSetDevice(c->ctx->device);
+    if (c->xs) (void)hipStreamSynchronize(c->xs);
+    for (void *p : c->halo) (void)hipFree(p);
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    if (c->e0) (void)hipEventDestroy(c->e0);
+    if (c->e1) (void)hipEventDestroy(c->e1);
+    if (c->x0) (void)hipEventDestroy(c->x0);
+    if (c->xs) (void)hipStreamDestroy(c->xs);
+    delete c;
+    return MID_OK;
+}
+
+extern "C" int mid_comm_rank(mid_comm *c, int *rank, int *world)
+{
+    MID_REQUIRE(c != nullptr, "comm_rank: comm is NULL");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return MID_OK;
+}
+
+// ncclSend + ncclRecv addressed to this very rank inside one group on the exchange stream: the halo exchange's call
+// pattern minus the wire -- what can be exercised on a one-GPU box (tests, smoke); also a cheap liveness probe of a comm.
+extern "C" int mid_comm_loopback(mid_comm *c, const void *src, void *dst, size_t bytes, void *stream)
+{
+    MID_REQUIRE(c && src && dst && bytes > 0, "comm_loopback: bad argument");
+    Bind b(c->ctx, stream);
+    if (b.rc) return b.rc;
+    MID_HIP(hipEventRecord(c->e0, b.s));
+    MID_HIP(hipStreamWaitEvent(c->xs, c->e0, 0));
+    MID_NCCL(rccl().GroupStart());
+    ncclResult_t r1 = rccl().Recv(dst, bytes, ncclUint8, c->rank, c->comm, c->xs);
+    ncclResult_t r2 = rccl().Send(src, bytes, ncclUint8, c->rank, c->comm, c->xs);
+    ncclResult_t r3 = rccl().GroupEnd();
+    if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess)
+        return set_error(MID_ERR_HIP, "comm_loopback: ncclRecv/ncclSend/ncclGroupEnd: %s / %s / %s", rccl().GetErrorString(r1), rccl().GetErrorString(r2), rccl().GetErrorString(r3));
+    MID_HIP(hipEventRecord(c->e1, c->xs));
+    MID_HIP(hipStreamWaitEvent(b.s, c->e1, 0));
+    return MID_OK;
+}
+
+extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, const void *const *block, int n_frames, int k,
+                                        mid_pixel *const *out, void *stream)
+{
+    MID_REQUIRE(c && p && n_frames >= 1 && k >= 0, "nlm_temporal_sharded: bad argument");
+    Bind b(c->ctx, stream);
+    if (b.rc) return b.rc;
+    int start, count;
+    block_of(n_frames, c->world, c->rank, start, count);
+    MID_REQUIRE(count == 0 || (block && out), "nlm_temporal_sharded: NULL table");
+    MID_REQUIRE(p->width > 0 && p->height > 0 && (p->format == MID_FMT_RGBA32F || p->format == MID_FMT_RGBA8), "nlm_temporal_sharded: bad params");
+    for (int i = 0; i < count; ++i) MID_REQUIRE(block[i] && out[i], "nlm_temporal_sharded: frame %d of the block is NULL", i);
+    const size_t frame_bytes = (size_t)p->width * p->height * (p->format == MID_FMT_RGBA8 ? 4 : 16);
+
+    std::vector<Xfer> rv, sd;
+    if (c->world > 1) halo_plan(n_frames, c->world, k, c->rank, rv, sd);
+    c->last_recv = rv.size() * frame_bytes; c->last_sent = sd.size() * frame_bytes; c->timed = false;
+
+    // receive buffers (kept across calls; a call's receives are ordered after the previous call's last readers through
+    // e0: calls on one communicator must be issued on one stream, or be separated by a synchronisation)
+    if (frame_bytes > c->halo_bytes) { for (void *q : c->halo) (void)hipFree(q); c->halo.clear(); c->halo_bytes = frame_bytes; }
+    while (c->halo.size() < rv.size()) { void *q = nullptr; MID_HIP(hipMalloc(&q, c->halo_bytes)); c->halo.push_back(q); }
+
+    if (!rv.empty() || !sd.empty()) {
+        MID_HIP(hipEventRecord(c->e0, b.s));                       // the block's frames (and the halo buffers' last readers) are done
+        MID_HIP(hipStreamWaitEvent(c->xs, c->e0, 0));
+        MID_HIP(hipEventRecord(c->x0, c->xs));
+        MID_NCCL(rccl().GroupStart());
+        ncclResult_t bad = ncclSuccess;
+        for (size_t i = 0; i < rv.size() && bad == ncclSuccess; ++i) bad = rccl().Recv(c->halo[i], frame_bytes, ncclUint8, rv[i].peer, c->comm, c->xs);
+        for (size_t i = 0; i < sd.size() && bad == ncclSuccess; ++i) bad = rccl().Send(block[sd[i].frame - start], frame_bytes, ncclUint8, sd[i].peer, c->comm, c->xs);
+        ncclResult_t end = rccl().GroupEnd();                      // always closed, even after a failed call inside
+        if (bad != ncclSuccess || end != ncclSuccess)
+            return set_error(MID_ERR_HIP, "halo exchange: %s", rccl().GetErrorString(bad != ncclSuccess ? bad : end));
+        MID_HIP(hipEventRecord(c->e1, c->xs));
+        c->timed = true;
+    }
+    if (count == 0) return MID_OK;
+
+    std::vector<Launch> plan;
+    launch_plan(n_frames, c->world, k, c->rank, plan);
+    auto frame_ptr = [&](int f) -> const void * {
+        if (f >= start && f < start + count) return block[f - start];
+        for (size_t i = 0; i < rv.size(); ++i) if (rv[i].frame == f) return c->halo[i];
+        return nullptr;
+    };
+    for (int phase = 1; phase >= 0; --phase) {                    // interior launches first, then (after the halo) the boundary ones
+        if (phase == 0 && c->timed) MID_HIP(hipStreamWaitEvent(b.s, c->e1, 0));
+        for (const Launch &L : plan) {
+            if (L.interior != phase) continue;
+            std::vector<const void *> tbl(L.w_hi - L.w_lo + 1);
+            for (int f = L.w_lo; f <= L.w_hi; ++f) {
+                tbl[f - L.w_lo] = frame_ptr(f);
+                MID_REQUIRE(tbl[f - L.w_lo], "nlm_temporal_sharded: frame %d is neither in the block nor in the halo (plan error)", f);
+            }
+            if (int rc = mid_nlm_temporal(c->ctx, p, tbl.data(), (int)tbl.size(), k, L.first, L.count, out + L.off, b.s)) return rc;
+        }
+    }
+    return MID_OK;
+}
+
+extern "C" int mid_comm_last_exchange(mid_comm *c, size_t *bytes_recv, size_t *bytes_sent, float *exchange_ms)
+{
+    MID_REQUIRE(c != nullptr, "comm_last_exchange: comm is NULL");
+    if (bytes_recv) *bytes_recv = c->last_recv;
+    if (bytes_sent) *bytes_sent = c->last_sent;
+    if (exchange_ms) {
+        *exchange_ms = 0.f;
+        if (c->timed) {
+            Bind b(c->ctx, nullptr);
+            if (b.rc) return b.rc;
+            MID_HIP(hipEventSynchronize(c->e1));
+            MID_HIP(hipEventElapsedTime(exchange_ms, c->x0, c->e1));
+        }
+    }
+    return MID_OK;
+}

@@ -209,6 +209,43 @@ int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const void *host_t
                        const void *const *host_frames, int n_frames, mid_pixel *host_out,
                        int overlap, float *timings_ms);
 
+/* ---- 8e: an animation sharded over GPUs (frame blocks + RCCL halo) ----------------------------
+ * New capability with the reference's multi-frame semantics (the reference is single-device: deviceId{0},
+ * src/main.cpp:1321; its neighbour-frame loop is src/main.cpp:1577-1606).  One rank per GPU owns a contiguous block of
+ * an n-frame sequence, resident in its HBM; temporal NLM over t-k..t+k needs the k frames on either side of the block,
+ * which are exchanged GPU to GPU in ONE step (ncclSend/ncclRecv in one group, point to point over xGMI) -- no other
+ * collective.  Interior outputs are launched while the halo is in flight, boundary outputs after it.
+ * RCCL is loaded at run time on the first mid_comm_* call (no link-time dependency; MID_ERR_UNSUPPORTED if absent).
+ *
+ * mid_shard_block: the partition -- rank r owns frames [start, start+count), the first n % world ranks one extra.
+ * mid_shard_halo_plan / mid_shard_launch_plan: the exchange and the launches of one rank as pure data (host only, no
+ *   GPU): receives/sends as (peer rank, global frame id) in issue order; launch rows {interior, w_lo, w_hi, first,
+ *   count, out_offset}: frames w_lo..w_hi form the table handed to mid_nlm_temporal, outputs are table entries
+ *   [first, first+count), stored at block-relative out_offset.  `cap` = capacity of the caller's arrays.
+ * mid_comm_unique_id + mid_comm_create: one process per GPU (rank 0 makes the id and hands it to the others out of
+ *   band -- a file, MPI, torch.distributed); mid_comm_create_all: one process, one context per device.
+ * mid_nlm_temporal_sharded: `block` = this rank's `count` device frames in order, `out` = `count` device outputs.
+ *   Asynchronous on `stream`; every rank of the communicator must call it with the same n_frames, k and frame size.
+ *   Calls on one communicator must be issued on one stream (the receive buffers are reused).  Results are bit-identical
+ *   to one mid_nlm_temporal over the whole sequence (same kernels, same tile shape).
+ * mid_comm_loopback: a send+receive addressed to this very rank (the exchange's call pattern without the wire).
+ * mid_comm_last_exchange: bytes received/sent by the last sharded call and (waits for it) the exchange's duration. */
+typedef struct mid_comm mid_comm;
+#define MID_COMM_ID_BYTES 128
+int mid_shard_block(int n_frames, int world, int rank, int *start, int *count);
+int mid_shard_halo_plan(int n_frames, int world, int k, int rank, int cap,
+                        int *recv_peer, int *recv_frame, int *n_recv, int *send_peer, int *send_frame, int *n_send);
+int mid_shard_launch_plan(int n_frames, int world, int k, int rank, int cap, int *rows /* cap x 6 ints */, int *n_rows);
+int mid_comm_unique_id(uint8_t id[MID_COMM_ID_BYTES]);
+int mid_comm_create(mid_ctx *ctx, const uint8_t id[MID_COMM_ID_BYTES], int rank, int world, mid_comm **out);
+int mid_comm_create_all(mid_ctx *const *ctxs, int world, mid_comm **out /* world entries */);
+int mid_comm_destroy(mid_comm *comm);
+int mid_comm_rank(mid_comm *comm, int *rank, int *world);
+int mid_comm_loopback(mid_comm *comm, const void *src, void *dst, size_t bytes, void *stream);
+int mid_nlm_temporal_sharded(mid_comm *comm, const mid_nlm_params *p, const void *const *block /* count device frames */,
+                             int n_frames, int k, mid_pixel *const *out /* count device frames */, void *stream);
+int mid_comm_last_exchange(mid_comm *comm, size_t *bytes_recv, size_t *bytes_sent, float *exchange_ms);
+
 /* ---- 8f-2: image files ------------------------------------------------------------------
  * mid_image_load = LoadImages (src/main.cpp:145-229): ".exr" -> RGBA32F (tinyexr LoadEXR: missing
  * alpha = 1), anything else is decoded as PNG -> RGBA8 (lodepng::decode).  `data` is host memory

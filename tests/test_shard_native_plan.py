@@ -1,0 +1,72 @@
+"""CPU suite: the C++ side of the frame-block sharding (csrc/sharded.cpp) as pure data -- partition, halo exchange plan
+and launch plan through the C-ABI (mid_shard_*), held against the Python statements the gloo tests pin
+(image_denoising_filter_amd/sharding.py) and against the properties RCCL needs: between any two ranks the sends of one
+are, in order, the receives of the other (RCCL matches a pair's sends and receives in issue order), every frame a rank
+needs arrives exactly once, and the launches cover every output exactly once using only frames the rank then holds."""
+import itertools
+
+import pytest
+
+import image_denoising_filter_amd as mid
+from image_denoising_filter_amd import sharding
+
+CASES = [(n, w, k) for n in (1, 2, 3, 5, 8, 11, 16, 23, 64) for w in (1, 2, 3, 4, 8) for k in (0, 1, 2, 3, 5)]
+
+
+def test_partition_matches_python_and_covers_the_sequence():
+    for n, world in itertools.product(range(0, 70), (1, 2, 3, 4, 5, 8, 16)):
+        parts = [mid.shard_block(n, world, r) for r in range(world)]
+        assert parts == sharding.partition(n, world)
+        assert sum(c for _, c in parts) == n and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+
+
+@pytest.mark.parametrize("n,world,k", CASES)
+def test_halo_plan_matches_python_and_pairs_up_in_issue_order(n, world, k):
+    plans = [mid.shard_halo_plan(n, world, k, r) for r in range(world)]
+    parts = sharding.partition(n, world)
+    for r, (recv, send) in enumerate(plans):
+        if world > 1 and k > 0 and parts[r][1] > 0:
+            precv, psend = sharding.halo_plan(n, world, k, r)
+            assert sorted(recv) == sorted((p, f) for p, ids in precv for f in ids)
+            assert sorted(send) == sorted((p, f) for p, ids in psend for f in ids)
+        else:
+            assert recv == [] and (send == [] or parts[r][1] > 0)
+        s, c = parts[r]
+        need = [f for f in range(max(0, s - k), min(n - 1, s + c - 1 + k) + 1) if not s <= f < s + c] if c and world > 1 else []
+        assert [f for _, f in recv] == need                      # every needed frame exactly once, ascending
+        assert all(parts[p][0] <= f < parts[p][0] + parts[p][1] for p, f in recv)   # from its owner
+        assert all(s <= f < s + c for _, f in send)              # a rank only sends what it owns
+    for a, b in itertools.permutations(range(world), 2):
+        a_to_b = [f for p, f in plans[a][1] if p == b]
+        b_from_a = [f for p, f in plans[b][0] if p == a]
+        assert a_to_b == b_from_a, (a, b, a_to_b, b_from_a)
+
+
+@pytest.mark.parametrize("n,world,k", CASES)
+def test_launch_plan_matches_python_and_only_touches_resident_frames(n, world, k):
+    for r in range(world):
+        plan = mid.shard_launch_plan(n, world, k, r)
+        assert plan == [tuple(x) for x in sharding.block_launch_plan(n, world, k, r)]
+        s, c = mid.shard_block(n, world, r)
+        held_after_halo = set(range(s, s + c)) | {f for _, f in mid.shard_halo_plan(n, world, k, r)[0]}
+        covered = []
+        for phase, w_lo, w_hi, first, cnt, off in plan:
+            table = set(range(w_lo, w_hi + 1))
+            assert table <= (set(range(s, s + c)) if phase == "interior" else held_after_halo)
+            for t in range(cnt):
+                g = w_lo + first + t                              # global id of this output
+                assert g == s + off + t
+                # its window t-k..t+k, clipped at the SEQUENCE ends only, must lie inside the table
+                assert set(range(max(0, g - k), min(n - 1, g + k) + 1)) <= table
+                covered.append(g)
+        assert sorted(covered) == list(range(s, s + c))
+
+
+def test_argument_errors_and_no_gpu_behaviour():
+    import ctypes
+    a = ctypes.c_int()
+    assert mid.lib.mid_shard_block(4, 0, 0, ctypes.byref(a), ctypes.byref(a)) == 1
+    assert mid.lib.mid_shard_block(4, 2, 2, ctypes.byref(a), ctypes.byref(a)) == 1
+    assert mid.lib.mid_comm_create(None, None, 0, 1, None) == 1          # NULL context: rejected before RCCL is even loaded
+    assert mid.lib.mid_nlm_temporal_sharded(None, None, None, 1, 0, None, None) == 1
+    assert mid.lib.mid_comm_destroy(None) == 0

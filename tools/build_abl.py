@@ -15,7 +15,7 @@ ABL = {
     6: [("load(n, rowp + sx);", "load(n, rowp);")],
 }
 objs = [os.path.join(ROOT, "build", o) for o in
-        "capi.cpp.o pointwise.hip.o bilateral.hip.o pipeline.cpp.o codec/png.cpp.o codec/exr.cpp.o codec/piz.cpp.o codec/image_capi.cpp.o".split()]
+        "capi.cpp.o pointwise.hip.o bilateral.hip.o pipeline.cpp.o sharded.cpp.o codec/png.cpp.o codec/exr.cpp.o codec/piz.cpp.o codec/image_capi.cpp.o".split()]
 flags = "-x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp".split()
 for n in [int(x) for x in sys.argv[1:]] or sorted(ABL):
     s = src

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 name, src_rel, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
-ALL = "capi.cpp pointwise.hip bilateral.hip nlm.hip pipeline.cpp codec/png.cpp codec/exr.cpp codec/piz.cpp codec/image_capi.cpp".split()
+ALL = "capi.cpp pointwise.hip bilateral.hip nlm.hip pipeline.cpp sharded.cpp codec/png.cpp codec/exr.cpp codec/piz.cpp codec/image_capi.cpp".split()
 assert src_rel in ALL, src_rel
 base = "-x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function".split()
 if src_rel == "nlm.hip":
@@ -22,5 +22,5 @@ subprocess.run(["/opt/rocm/bin/hipcc"] + base + extra + ["-I" + os.path.join(ROO
                 os.path.join(ROOT, "image_denoising_filter_amd/csrc", src_rel), "-o", o], check=True)
 objs = [o if s == src_rel else os.path.join(ROOT, "build", s + ".o") for s in ALL]
 out = os.path.join(d, f"libmi_{name}.so")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-lz"], check=True)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-lz", "-ldl"], check=True)
 print("built", os.path.relpath(out, ROOT), "with", src_rel, " ".join(extra))

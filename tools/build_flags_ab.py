@@ -15,7 +15,7 @@ SETS = {
     8: ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
 }
 objs = [os.path.join(ROOT, "build", o) for o in
-        "capi.cpp.o pointwise.hip.o bilateral.hip.o pipeline.cpp.o codec/png.cpp.o codec/exr.cpp.o codec/piz.cpp.o codec/image_capi.cpp.o".split()]
+        "capi.cpp.o pointwise.hip.o bilateral.hip.o pipeline.cpp.o sharded.cpp.o codec/png.cpp.o codec/exr.cpp.o codec/piz.cpp.o codec/image_capi.cpp.o".split()]
 base = "-x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize".split()
 d = os.path.join(ROOT, "build", "abl")
 os.makedirs(d, exist_ok=True)
@@ -28,7 +28,7 @@ def build(n):
                        capture_output=True, text=True)
     if r.returncode:
         return n, "compile failed: " + r.stderr[-300:]
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(d, "libmi_f%d.so" % n)] + objs + [o, "-lz"], check=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(d, "libmi_f%d.so" % n)] + objs + [o, "-lz", "-ldl"], check=True)
     return n, "ok " + " ".join(SETS[n])
 
 

@@ -207,7 +207,7 @@ class _DryContext:
         self.launches.append((len(frame_ptrs), k, first, count))
 
 
-def dry_run(args):
+def dry_run(args, json_out):
     """The N-rank control flow of main() on CPU tensors over gloo: process group, barriers, the timed loop,
     max-over-ranks, the temporal step with its overlapped halo exchange, one JSON line from rank 0."""
     from image_denoising_filter_amd import sharding
@@ -259,9 +259,20 @@ def dry_run(args):
         dist.barrier()
     if rank == 0:
         print(json.dumps({"metric": "dry run (no kernels)", "dry_run": True, "n_gpus": world, "steps": args.steps,
-                          "value": None, "elapsed_s": round(elapsed, 6), "launches_rank0": len(ctx.launches)}))
+                          "value": None, "elapsed_s": round(elapsed, 6), "launches_rank0": len(ctx.launches)}), file=json_out, flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL prints a version banner on stdout when a
+    communicator is created through the C API (seen on the GPU box: 'RCCL version : ...', 'Librccl path : ...') -- so file
+    descriptor 1 is pointed at stderr for the whole run and the JSON line is written to a private duplicate of the
+    original stdout.  Returns that file object."""
+    sys.stdout.flush()
+    out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return out
 
 
 def _free_port():
@@ -343,8 +354,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher above us: become one, BEFORE anything touches the GPU (see launch_ranks)
         sys.exit(launch_ranks(args.gpus))
+    json_out = claim_stdout()
     if args.dry_run:
-        return dry_run(args)
+        return dry_run(args, json_out)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -478,7 +490,7 @@ def main():
         if printed.acquire(blocking=False) and rank == 0:
             res["also"] = also
             res.setdefault("cpu_baseline", None)
-            print(json.dumps(res), flush=True)
+            print(json.dumps(res), file=json_out, flush=True)
 
     def on_timeout():
         also["error"] = "extras did not finish within 300 s; line emitted by the watchdog"
@@ -633,6 +645,65 @@ def main():
                                                if world > 1 else "none (1 rank)"}
 
         guarded("temporal", extra_temporal)
+
+        def extra_temporal_native():
+            # The same job through the C++ path (csrc/sharded.cpp: mid_comm_create + mid_nlm_temporal_sharded -- RCCL bound by
+            # dlopen, ncclSend/ncclRecv in one group on the library's exchange stream, interior launches meanwhile), with its
+            # outputs compared bit for bit against a plain launch over block + halo frames fetched by the torch path.
+            if rehearse:
+                also["temporal_nlm_k2_native"] = {"skipped": "rehearsal: RCCL refuses two ranks on one device"}
+                return
+            k, n_seq = 2, SEQ_FRAMES
+            start, count = sharding.partition(n_seq, world)[rank]
+            seq = [synth_frames(1, 1000 + g, device, shift=2 * g)[0] for g in range(start, start + count)]
+            souts = [torch.empty((H, W, 4), device=device, dtype=torch.float32) for _ in range(count)]
+            idt = torch.zeros(mid.api.COMM_ID_BYTES, dtype=torch.uint8, device=coll_device)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(mid.comm_unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(idt, src=0)
+            with mid.Comm(ctx, bytes(idt.cpu().numpy().tobytes()), rank, world) as comm:
+                def step():
+                    comm.nlm_temporal_sharded_dev([f.data_ptr() for f in seq], [o.data_ptr() for o in souts], W, H, n_seq, k,
+                                                  HPARAM, SEARCH, PATCH, mid.FMT_RGBA32F, stream)
+                step()
+                torch.cuda.synchronize()
+                # cross-check: the torch.distributed path's frames (own block + halo) through ONE plain launch
+                have = sharding.exchange_halo(seq, n_seq, k)
+                fr, first = sharding.window_for_block(have, n_seq, k, start, count)
+                ref = [torch.empty((H, W, 4), device=device, dtype=torch.float32) for _ in range(count)]
+                ctx.nlm_temporal_dev([f.data_ptr() for f in fr], [o.data_ptr() for o in ref], W, H, HPARAM, SEARCH, PATCH, k, first, count,
+                                     mid.FMT_RGBA32F, stream)
+                torch.cuda.synchronize()
+                same = all(torch.equal(a, b) for a, b in zip(souts, ref))
+                barrier()
+                t1 = time.perf_counter()
+                reps = 3
+                for _ in range(reps):
+                    step()
+                    torch.cuda.synchronize()
+                barrier()
+                te = (time.perf_counter() - t1) / reps
+                recv, sent, xms = comm.last_exchange()
+            per_rank = [te, float(recv), float(sent), float(xms), 1.0 if same else 0.0]
+            if world > 1:
+                t = torch.tensor(per_rank, device=coll_device, dtype=torch.float64)
+                allr = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(allr, t)
+                rows = [[float(x) for x in a.tolist()] for a in allr]
+            else:
+                rows = [per_rank]
+            te = max(r[0] for r in rows)
+            also["temporal_nlm_k2_native"] = {"Mpixel/s_out": round(n_seq * NPIX / 1e6 / te, 1), "frames": n_seq,
+                                              "ms_per_sequence": round(te * 1e3, 3),
+                                              "halo_bytes_recv_per_rank": [int(r[1]) for r in rows],
+                                              "halo_bytes_sent_per_rank": [int(r[2]) for r in rows],
+                                              "exchange_ms_per_rank": [round(r[3], 4) for r in rows],
+                                              "bit_identical_to_single_launch_per_rank": [bool(r[4]) for r in rows],
+                                              "path": "C++: mid_comm_create (ncclCommInitRank via dlopen) + mid_nlm_temporal_sharded "
+                                                      "(ncclSend/ncclRecv in one group on the exchange stream, interior launches meanwhile)"}
+
+        guarded("temporal_native", extra_temporal_native)
 
         def extra_pipeline():
             if rank == 0 and world == 1:

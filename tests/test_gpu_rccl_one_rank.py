@@ -124,3 +124,20 @@ def test_bench_line_under_a_launcher_with_nccl_names_backend_and_devices(tmp_pat
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and "process_group" not in d["config"]
     assert d["roofline"]["kernel_ms_min"] <= d["roofline"]["avg_launch_ms"] <= d["roofline"]["kernel_ms_max"]
+
+
+def test_bench_stdout_is_exactly_one_json_line_with_the_native_rccl_extra(tmp_path):
+    """The whole 1-GPU bench with its extras -- among them the C++ RCCL path (a 1-rank communicator created through the
+    C-ABI, which makes RCCL print its version banner on stdout): stdout must still hold the JSON line and nothing else,
+    and the native path must report outputs bit-identical to the plain launch."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:2000]
+    d = json.loads(lines[0])
+    nat = d["also"]["temporal_nlm_k2_native"]
+    assert nat["bit_identical_to_single_launch_per_rank"] == [True] and nat["halo_bytes_recv_per_rank"] == [0]
+    assert not [k for k in d["also"] if k.endswith("_error")], d["also"]
+    assert d["also"]["bilateral_r8_texture_over_linear"] > 0

@@ -79,7 +79,10 @@ class _Have(dict):
 
 
 def _must_stage(tensor, group):
-    """Device tensors cannot travel over a backend that only moves host memory (gloo): stage them through the host."""
+    """Device tensors cannot travel over a backend that only moves host memory (gloo): stage them through the host.
+    The test is for a group whose backend IS "gloo".  A group created with a per-device backend map
+    ("cpu:gloo,cuda:nccl") reports that whole string: its device tensors go over nccl (RCCL) directly, which is what we
+    want, so it is deliberately not staged."""
     return bool(getattr(tensor, "is_cuda", False)) and dist.is_initialized() and dist.get_backend(group) == "gloo"
 
 

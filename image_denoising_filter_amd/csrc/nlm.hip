@@ -95,7 +95,7 @@ __device__ __forceinline__ float horizontal_box(float v)
 // so THREE workgroups share a CU (3 waves per SIMD instead of 2; the kernel needs 166 VGPRs when asked to, no spill).  The
 // offsets are visited in the same order (search row outer, search column inner), so the sums -- and the output bits --
 // are those of the single-pass kernel.
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0>
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0, int PF = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SYP > 0 ? 3 : 1, SYP > 0 ? 3 : 2)))
 void nlm_strip_kernel(const NlmArgs a)
 {
@@ -114,6 +114,7 @@ void nlm_strip_kernel(const NlmArgs a)
     const int LH = TILE_H + PW - 1 + SYPASS - 1;
     static_assert(PLO <= 0 && PHI >= 1 && (RTS || SHI - SLO >= 1), "ranges must contain 0");
     static_assert(!(SYP > 0 && SYM), "the symmetry ablation is single-pass");
+    static_assert(PF == 0 || (!SYM && SYP == 0), "the prefetching loop exists for the plain single-pass kernel");
 
     extern __shared__ float4 lds[];
 
@@ -208,7 +209,84 @@ void nlm_strip_kernel(const NlmArgs a)
             for (int m = 0; m < DR; ++m) n[m] = p[m * LW];
         };
 
-        if constexpr (SYM) {
+        if constexpr (PF > 0) {
+            // Software-pipelined tile reads (round 3).  In the plain loop an offset is load -> wait -> compute: its 14
+            // ds_read_b128 are issued and the wave waits for them at once, the other wave of the SIMD covering the gap
+            // alone -- at the single-wave issue rate (4.4 cycles per instruction against 2.2 for two waves,
+            // tools/microbench8.hip).  Here the reads of offset o+1 are issued right after the DISTANCE phase of offset o:
+            // the 6 patch-halo rows go back into the registers that phase has just finished with, the 8 centre rows (still
+            // needed by o's accumulate step) into a second set (+32 VGPRs), and the box sums, exp and accumulate of o
+            // (about 2/3 of an offset) run while they are in flight.  Arithmetic and order of operations are unchanged:
+            // identical output bits.
+            static_assert(DR - R == NL + NR, "halo rows");
+            constexpr int NH = DR - R;                                   // patch-halo rows: NL above, NR below
+            float4 hl[NH], c0[R], c1[R];
+            auto load_rows = [&](float4 (&h)[NH], float4 (&c)[R], const float4 *p) {
+#pragma unroll
+                for (int m = 0; m < NL; ++m) h[m] = p[m * LW];
+#pragma unroll
+                for (int k = 0; k < R; ++k) c[k] = p[(NL + k) * LW];
+#pragma unroll
+                for (int m = 0; m < NR; ++m) h[NL + m] = p[(NL + R + m) * LW];
+            };
+            auto dist = [&](const float4 (&h)[NH], const float4 (&c)[R], float (&D)[DR]) {
+#pragma unroll
+                for (int m = 0; m < DR; ++m) {
+                    const float4 &n = m < NL ? h[m] : (m < NL + R ? c[m - NL] : h[m - R]);
+                    const float dx = Tr[m] - n.x, dy = Tg[m] - n.y, dz = Tb[m] - n.z;
+                    D[m] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                }
+                // (halo alpha is never used: keep it formally live up to here so its read stays a ds_read_b128)
+#pragma unroll
+                for (int m = 0; m < NH; ++m) asm volatile("" ::"v"(h[m].w));
+            };
+            auto finish = [&](const float (&D)[DR], const float4 (&c)[R]) {
+                float V[R];
+                vertical_box<PW, R>(D, V);
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const float d = horizontal_box<PLO, PHI>(V[k]);
+                    const float wt = __builtin_amdgcn_exp2f(-d);
+                    acc[k].x = fmaf(c[k].x, wt, acc[k].x); acc[k].y = fmaf(c[k].y, wt, acc[k].y);
+                    acc[k].z = fmaf(c[k].z, wt, acc[k].z); acc[k].w = fmaf(c[k].w, wt, acc[k].w);
+                    accw[k] += wt;
+                }
+            };
+            const float4 *base = lds + (wv * R) * LW + lane;
+            const int n_off = SW * SW;
+            auto ptr_of = [&](int o) { const int sy = o / SW; return base + sy * LW + (o - sy * SW); };
+            load_rows(hl, c0, ptr_of(0));
+            // straight-line trips of two offsets (the centre-row sets alternate); every trip ends with offset o+2's rows in
+            // flight, so the last trip's prefetch is clamped to the last offset (a harmless re-read) and an odd count ends
+            // with one single-offset step
+            const int n_pair = n_off / 2;
+            for (int t = 0; t < n_pair; ++t) {
+                const int o = 2 * t;
+                {
+                    float D[DR];
+                    dist(hl, c0, D);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_rows(hl, c1, ptr_of(o + 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    finish(D, c0);
+                    __builtin_amdgcn_sched_barrier(0);      // (or the next offset's distance phase is hoisted up to the reads just issued)
+                }
+                {
+                    float D[DR];
+                    dist(hl, c1, D);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_rows(hl, c0, ptr_of(o + 2 < n_off ? o + 2 : n_off - 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    finish(D, c1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (n_off & 1) {
+                float D[DR];
+                dist(hl, c0, D);
+                finish(D, c0);
+            }
+        } else if constexpr (SYM) {
             float Ta[R];                                   // alpha of the lane's own centre texels (T carries rgb only)
 #pragma unroll
             for (int k = 0; k < R; ++k) Ta[k] = fetch_texture<FMT>(target, w, h, gx, yb + k).w;
@@ -401,7 +479,7 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
     }
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0>
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0, int PF = 0>
 static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
 {
     constexpr bool RTS = (SLO == 0 && SHI == 0);
@@ -410,7 +488,7 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
     const int SW = RTS ? a.shi - a.slo : SHI - SLO;
     const int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + (SYP > 0 ? SYP : SW) - 1;
     const size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
-    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, SYM, SYP>;
+    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, SYM, SYP, PF>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     // run-time-range instantiations are launched with different tile sizes: raise their limit to the device maximum once
@@ -460,6 +538,10 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
         if (!multi && variant == 11) return launch_strip<-10, 11, -3, 4, 8, 6, FMT, FUSED, false, 3, false, 5>(ctx, a, s);
         if (!multi && variant == 12) return launch_strip<-10, 11, -3, 4, 8, 6, FMT, FUSED, false, 3, false, 7>(ctx, a, s);
         if (!multi && variant == 13) return launch_strip<-10, 11, -3, 4, 8, 6, FMT, FUSED, false, 7, false, 7>(ctx, a, s);
+        if (variant == 14) {  // software-pipelined tile reads (PF)
+            if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 1, false, 0, 1>(ctx, a, s);
+            return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 1, false, 0, 1>(ctx, a, s);
+        }
 #endif
         if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3>(ctx, a, s);
         return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s);

@@ -124,7 +124,11 @@ CLASSES = {"nlm": {"dpp": 48 / 198, "trans": 8 / 198}, "bilateral": {"dpp": 0.0,
 # tools/microbench.hip / microbench5.hip measured at this kernel's occupancy: 2.9 / 4.85 / 8.4 at 2 waves per
 # SIMD (NLM), 2.5 / - / 8.4 at 8 waves per SIMD (bilateral).
 COST = {"floor": {"plain": 2.0, "dpp": 4.0, "trans": 8.0},
-        "nlm_measured": {"plain": 2.9, "dpp": 4.85, "trans": 8.4}, "bilateral_measured": {"plain": 2.5, "dpp": 4.4, "trans": 8.4}}
+        "nlm_measured": {"plain": 2.9, "dpp": 4.85, "trans": 8.4}, "bilateral_measured": {"plain": 2.5, "dpp": 4.4, "trans": 8.4},
+        # tools/microbench8.hip (round 3): cycles counted by the chip (s_memtime), clock measured beside them -- plain = the
+        # mix-weighted mean of two-source ops (2.25) and three-VGPR-source FMAs (2.54 at 2 waves/SIMD, 2.22 at 8)
+        "nlm_cycle_exact": {"plain": (82 * 2.25 + 60 * 2.54) / 142, "dpp": 4.39, "trans": 8.2},
+        "bilateral_cycle_exact": {"plain": 2.22, "dpp": 4.1, "trans": 8.1}}
 
 
 def durations_by_kernel():
@@ -169,6 +173,10 @@ def utilisation(key, cls):
         "valu_issue_util_at_measured_costs": round(priced(COST[cls + "_measured"]) / simd_cyc, 4),
         "valu_issue_util_at_measured_costs_def": "the same priced at the per-instruction issue costs the micro-benchmarks measured at this kernel's "
                                                  "occupancy (tools/microbench*.hip, DESIGN.md 3.1): ~1.0 means the kernel sits at the issue limit of its mix",
+        "valu_issue_util_at_cycle_exact_costs": round(priced(COST[cls + "_cycle_exact"]) / simd_cyc, 4),
+        "valu_issue_util_at_cycle_exact_costs_def": "the same priced at the issue costs tools/microbench8.hip measures in shader cycles at this kernel's "
+                                                    "occupancy (s_memtime; NLM at 2 waves/SIMD: two-source plain 2.25, three-source FMA 2.54, DPP add 4.39, "
+                                                    "v_exp_f32 8.2): the fraction of a perfectly fed vector pipe the kernel reaches at its instruction mix",
         "valu_active_share_of_wave_cycles": round(d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], 4),
         "valu_busy_gfx94x_formula": round(d["SQ_ACTIVE_INST_VALU"] * 4 / simd_cyc, 4),
         "valu_busy_gfx94x_formula_def": "SQ_ACTIVE_INST_VALU (quad-cycles, per wave) x4 / SIMD-cycles, rocprof's derived VALUBusy for gfx94x; it sums over "

@@ -16,15 +16,15 @@ namespace codec {
 
 namespace {
 
-constexpr int HUF_ENCBITS = 16, HUF_DECBITS = 14;
-constexpr int HUF_ENCSIZE = (1 << HUF_ENCBITS) + 1, HUF_DECSIZE = 1 << HUF_DECBITS, HUF_DECMASK = HUF_DECSIZE - 1;
-constexpr int SHORT_ZEROCODE_RUN = 59, LONG_ZEROCODE_RUN = 63, SHORTEST_LONG_RUN = 2 + LONG_ZEROCODE_RUN - SHORT_ZEROCODE_RUN;
-constexpr int BITMAP_SIZE = 8192;
+constexpr int kSymbolBits = 16, kFastBits = 14;
+constexpr int kSymbolCount = (1 << kSymbolBits) + 1, kFastEntries = 1 << kFastBits, kFastMask = kFastEntries - 1;
+constexpr int kShortZeroRunCode = 59, kLongZeroRunCode = 63, kLongZeroRunBase = 2 + kLongZeroRunCode - kShortZeroRunCode;
+constexpr int kBitmapBytes = 8192;
 
-struct HufDec {
-    int len = 0;                 // short code: its length
-    int lit = 0;                 // short code: symbol; long codes: number of candidates
-    std::vector<int> p;          // long codes: candidate symbols
+struct FastEntry {                  // one slot of the kFastBits-bit prefix table
+    int length = 0;                 // code no longer than the prefix: its length (0 = none)
+    int symbol = 0;                 // that code's symbol; for longer codes: how many share this prefix
+    std::vector<int> candidates;    // longer codes sharing this prefix: their symbols
 };
 
 struct BitReader {
@@ -44,75 +44,75 @@ struct BitReader {
     }
 };
 
-inline int huf_length(uint64_t code) { return (int)(code & 63); }
-inline uint64_t huf_code(uint64_t code) { return code >> 6; }
+inline int code_length(uint64_t code) { return (int)(code & 63); }
+inline uint64_t code_bits(uint64_t code) { return code >> 6; }
 
 // Code lengths -> canonical codes (packed as length | code << 6).
-void canonical_code_table(std::vector<uint64_t> &hcode)
+void assign_canonical_codes(std::vector<uint64_t> &codes)
 {
     uint64_t n[59] = {0};
-    for (int i = 0; i < HUF_ENCSIZE; ++i) n[hcode[i]] += 1;
+    for (int i = 0; i < kSymbolCount; ++i) n[codes[i]] += 1;
     uint64_t c = 0;
     for (int i = 58; i > 0; --i) {
         const uint64_t nc = (c + n[i]) >> 1;
         n[i] = c;
         c = nc;
     }
-    for (int i = 0; i < HUF_ENCSIZE; ++i) {
-        const int l = (int)hcode[i];
-        if (l > 0) hcode[i] = (uint64_t)l | (n[l]++ << 6);
+    for (int i = 0; i < kSymbolCount; ++i) {
+        const int l = (int)codes[i];
+        if (l > 0) codes[i] = (uint64_t)l | (n[l]++ << 6);
     }
 }
 
-bool unpack_enc_table(const uint8_t *&p, const uint8_t *end, int im, int iM, std::vector<uint64_t> &hcode, std::string &err)
+bool read_length_table(const uint8_t *&p, const uint8_t *end, int im, int iM, std::vector<uint64_t> &codes, std::string &err)
 {
-    std::fill(hcode.begin(), hcode.end(), 0);
+    std::fill(codes.begin(), codes.end(), 0);
     BitReader br{p, end};
     for (; im <= iM; ++im) {
         const uint64_t l = br.get(6);
         if (!br.ok) { err = "exr/piz: truncated Huffman table"; return false; }
-        hcode[im] = l;
-        int zerun = 0;
-        if (l == (uint64_t)LONG_ZEROCODE_RUN) zerun = (int)br.get(8) + SHORTEST_LONG_RUN;
-        else if (l >= (uint64_t)SHORT_ZEROCODE_RUN) zerun = (int)l - SHORT_ZEROCODE_RUN + 2;
+        codes[im] = l;
+        int zero_run = 0;
+        if (l == (uint64_t)kLongZeroRunCode) zero_run = (int)br.get(8) + kLongZeroRunBase;
+        else if (l >= (uint64_t)kShortZeroRunCode) zero_run = (int)l - kShortZeroRunCode + 2;
         if (!br.ok) { err = "exr/piz: truncated Huffman table"; return false; }
-        if (zerun) {
-            if (im + zerun > iM + 1) { err = "exr/piz: Huffman table overruns"; return false; }
-            while (zerun--) hcode[im++] = 0;
+        if (zero_run) {
+            if (im + zero_run > iM + 1) { err = "exr/piz: Huffman table overruns"; return false; }
+            while (zero_run--) codes[im++] = 0;
             --im;
         }
     }
     p = br.in;
-    canonical_code_table(hcode);
+    assign_canonical_codes(codes);
     return true;
 }
 
-bool build_dec_table(const std::vector<uint64_t> &hcode, int im, int iM, std::vector<HufDec> &dec, std::string &err)
+bool build_fast_table(const std::vector<uint64_t> &codes, int im, int iM, std::vector<FastEntry> &dec, std::string &err)
 {
     for (; im <= iM; ++im) {
-        const uint64_t c = huf_code(hcode[im]);
-        const int l = huf_length(hcode[im]);
+        const uint64_t c = code_bits(codes[im]);
+        const int l = code_length(codes[im]);
         if (l == 0) continue;
         if (c >> l) { err = "exr/piz: invalid Huffman code"; return false; }
-        if (l > HUF_DECBITS) {
-            HufDec &pl = dec[(size_t)(c >> (l - HUF_DECBITS))];
-            if (pl.len) { err = "exr/piz: invalid Huffman table"; return false; }
-            pl.lit++;
-            pl.p.push_back(im);
+        if (l > kFastBits) {
+            FastEntry &pl = dec[(size_t)(c >> (l - kFastBits))];
+            if (pl.length) { err = "exr/piz: invalid Huffman table"; return false; }
+            pl.symbol++;
+            pl.candidates.push_back(im);
         } else {
-            const size_t base = (size_t)(c << (HUF_DECBITS - l));
-            for (size_t i = 0; i < ((size_t)1 << (HUF_DECBITS - l)); ++i) {
-                HufDec &pl = dec[base + i];
-                if (pl.len || !pl.p.empty()) { err = "exr/piz: invalid Huffman table"; return false; }
-                pl.len = l;
-                pl.lit = im;
+            const size_t base = (size_t)(c << (kFastBits - l));
+            for (size_t i = 0; i < ((size_t)1 << (kFastBits - l)); ++i) {
+                FastEntry &pl = dec[base + i];
+                if (pl.length || !pl.candidates.empty()) { err = "exr/piz: invalid Huffman table"; return false; }
+                pl.length = l;
+                pl.symbol = im;
             }
         }
     }
     return true;
 }
 
-bool huf_decode(const std::vector<uint64_t> &hcode, const std::vector<HufDec> &dec, const uint8_t *in, const uint8_t *file_end,
+bool decode_symbols(const std::vector<uint64_t> &codes, const std::vector<FastEntry> &dec, const uint8_t *in, const uint8_t *file_end,
                 int ni, int rlc, size_t no, uint16_t *out, std::string &err)
 {
     uint64_t c = 0;
@@ -137,18 +137,18 @@ bool huf_decode(const std::vector<uint64_t> &hcode, const std::vector<HufDec> &d
     while (in < ie) {
         c = (c << 8) | *in++;
         lc += 8;
-        while (lc >= HUF_DECBITS) {
-            const HufDec &pl = dec[(size_t)((c >> (lc - HUF_DECBITS)) & HUF_DECMASK)];
-            if (pl.len) {
-                lc -= pl.len;
-                if (!get_code(pl.lit)) { err = "exr/piz: corrupt Huffman data"; return false; }
+        while (lc >= kFastBits) {
+            const FastEntry &pl = dec[(size_t)((c >> (lc - kFastBits)) & kFastMask)];
+            if (pl.length) {
+                lc -= pl.length;
+                if (!get_code(pl.symbol)) { err = "exr/piz: corrupt Huffman data"; return false; }
             } else {
-                if (pl.p.empty()) { err = "exr/piz: corrupt Huffman data (no such code)"; return false; }
+                if (pl.candidates.empty()) { err = "exr/piz: corrupt Huffman data (no such code)"; return false; }
                 bool found = false;
-                for (int sym : pl.p) {
-                    const int l = huf_length(hcode[sym]);
+                for (int sym : pl.candidates) {
+                    const int l = code_length(codes[sym]);
                     while (lc < l && in < ie) { c = (c << 8) | *in++; lc += 8; }
-                    if (lc >= l && huf_code(hcode[sym]) == ((c >> (lc - l)) & ((1ull << l) - 1))) {
+                    if (lc >= l && code_bits(codes[sym]) == ((c >> (lc - l)) & ((1ull << l) - 1))) {
                         lc -= l;
                         if (!get_code(sym)) { err = "exr/piz: corrupt Huffman data"; return false; }
                         found = true;
@@ -163,11 +163,11 @@ bool huf_decode(const std::vector<uint64_t> &hcode, const std::vector<HufDec> &d
     c >>= i;
     lc -= i;
     while (lc > 0) {
-        const HufDec &pl = dec[(size_t)((c << (HUF_DECBITS - lc)) & HUF_DECMASK)];
-        if (!pl.len) { err = "exr/piz: corrupt Huffman data (tail)"; return false; }
-        lc -= pl.len;
+        const FastEntry &pl = dec[(size_t)((c << (kFastBits - lc)) & kFastMask)];
+        if (!pl.length) { err = "exr/piz: corrupt Huffman data (tail)"; return false; }
+        lc -= pl.length;
         if (lc < 0) { err = "exr/piz: corrupt Huffman data (tail)"; return false; }
-        if (!get_code(pl.lit)) { err = "exr/piz: corrupt Huffman data"; return false; }
+        if (!get_code(pl.symbol)) { err = "exr/piz: corrupt Huffman data"; return false; }
     }
     if ((size_t)(out - outb) != no) { err = "exr/piz: Huffman data decodes to the wrong size"; return false; }
     return true;
@@ -180,14 +180,14 @@ bool huf_uncompress(const uint8_t *comp, size_t ncomp, uint16_t *raw, size_t nra
     uint32_t hdr[5];
     memcpy(hdr, comp, 20);
     const int im = (int)hdr[0], iM = (int)hdr[1], nbits = (int)hdr[3];
-    if (im < 0 || im >= HUF_ENCSIZE || iM < 0 || iM >= HUF_ENCSIZE || im > iM || nbits < 0) { err = "exr/piz: bad Huffman header"; return false; }
+    if (im < 0 || im >= kSymbolCount || iM < 0 || iM >= kSymbolCount || im > iM || nbits < 0) { err = "exr/piz: bad Huffman header"; return false; }
     const uint8_t *p = comp + 20, *end = comp + ncomp;
-    std::vector<uint64_t> hcode(HUF_ENCSIZE);
-    if (!unpack_enc_table(p, end, im, iM, hcode, err)) return false;
+    std::vector<uint64_t> codes(kSymbolCount);
+    if (!read_length_table(p, end, im, iM, codes, err)) return false;
     if ((size_t)nbits > 8 * (size_t)(end - p)) { err = "exr/piz: Huffman bit count beyond the block"; return false; }
-    std::vector<HufDec> dec(HUF_DECSIZE);
-    if (!build_dec_table(hcode, im, iM, dec, err)) return false;
-    return huf_decode(hcode, dec, p, end, nbits, iM, nraw, raw, err);
+    std::vector<FastEntry> dec(kFastEntries);
+    if (!build_fast_table(codes, im, iM, dec, err)) return false;
+    return decode_symbols(codes, dec, p, end, nbits, iM, nraw, raw, err);
 }
 
 // ---- wavelet ---------------------------------------------------------------------------------
@@ -271,8 +271,8 @@ bool piz_decode_block(const uint8_t *comp, size_t ncomp, int width, int nl, cons
     memcpy(&min_nz, comp, 2);
     memcpy(&max_nz, comp + 2, 2);
     const uint8_t *p = comp + 4, *end = comp + ncomp;
-    std::vector<uint8_t> bitmap(BITMAP_SIZE, 0);
-    if (max_nz >= BITMAP_SIZE) { err = "exr/piz: bad bitmap range"; return false; }
+    std::vector<uint8_t> bitmap(kBitmapBytes, 0);
+    if (max_nz >= kBitmapBytes) { err = "exr/piz: bad bitmap range"; return false; }
     if (min_nz <= max_nz) {
         const size_t n = (size_t)max_nz - min_nz + 1;
         if ((size_t)(end - p) < n) { err = "exr/piz: truncated bitmap"; return false; }

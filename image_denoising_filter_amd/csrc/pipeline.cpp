@@ -82,7 +82,10 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
     // Outputs could be filtered in batches of B frames per launch.  Measured on MI355X (16 x 1080p, 21x21/7x7):
     // B=1 2084 Mpixel/s, B=2 1341, B=4 1472, B=8 1403 -- coarser batches bunch the copies and lose overlap
     // while the kernel time barely changes, so one frame per launch it is (the indexing below stays general in B).
-    constexpr int B = 1;
+#ifndef MID_PIPE_B
+#define MID_PIPE_B 1            /* build-time only (tools/build_alt.py pipe_b2 pipeline.cpp -DMID_PIPE_B=2): the A/B behind the figures above */
+#endif
+    const int B = MID_PIPE_B > count ? count : MID_PIPE_B;
     const int nb = (count + B - 1) / B;
     constexpr int DEPTH = 4;                                  // batches in flight per stage
     const int ring = n_up < 2 * k + DEPTH * B ? n_up : 2 * k + DEPTH * B;

@@ -133,6 +133,11 @@ class Timers:
             out.append(v.value)
         return out
 
+    def close(self):
+        for p in self.t:
+            self.lib.mid_timer_destroy(p)
+        self.t = []
+
 
 def _cpu_reference_bilateral(oracle):
     """The reference's own CPU bilateral loop (oracle/_ref, src/main.cpp:1827-1864, r=10, sigma 10/0.2,
@@ -444,6 +449,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = timers.ms()
+    timers.close()
     avg_launch_s = sum(kernel_ms) / len(kernel_ms) / 1e3
 
     value = world * F * args.steps * NPIX / 1e6 / elapsed
@@ -516,7 +522,9 @@ def main():
                 fn()
             tm.tock(0, stream)
             torch.cuda.synchronize()
-            return tm.ms()[0] / n / 1e3
+            ms = tm.ms()[0]
+            tm.close()
+            return ms / n / 1e3
 
         def extra_bilateral():
             # The two layouts run the same inner loop (identical opcode stream; only the tile fill differs).  Timed one after

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
                     if (j < -R || j > R) continue;
                     const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
                     const float arg = fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, sij[j < 0 ? -j : j])));
-                    const float wt = __builtin_amdgcn_exp2f(arg);
+                    const float wt = exp2_hw(arg);
                     acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
                     acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
                     accw[k] += wt;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512) void bilateral_rt_kernel(const BilArgs a, cons
                     const int j = m - R - k;
                     if (j < -R || j > R) continue;               // wave-uniform
                     const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
-                    const float wt = __builtin_amdgcn_exp2f(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, fmaf(a.ks, (float)(j * j), si)))));
+                    const float wt = exp2_hw(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, fmaf(a.ks, (float)(j * j), si)))));
                     acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
                     acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
                     accw[k] += wt;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void bilateral_generic_kernel(const BilArgs a,
                 }
                 const float dx = ctr.x - g.x, dy = ctr.y - g.y, dz = ctr.z - g.z;
                 const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                const float wt = __builtin_amdgcn_exp2f(fmaf(d2, a.kc, a.ks * (float)(i * i + j * j)));
+                const float wt = exp2_hw(fmaf(d2, a.kc, a.ks * (float)(i * i + j * j)));
                 acc.x = fmaf(c.x, wt, acc.x); acc.y = fmaf(c.y, wt, acc.y);
                 acc.z = fmaf(c.z, wt, acc.z); acc.w = fmaf(c.w, wt, acc.w);
                 accw += wt;

@@ -170,6 +170,33 @@ __device__ __forceinline__ unsigned xcd_remap_in_frame(unsigned t, unsigned tile
     return start + ((t - first_c) >> 3);
 }
 
+// 2^x on the transcendental pipe.  On gfx950 a v_exp_f32 that is followed IMMEDIATELY by another vector instruction of the
+// same wave costs about 7 cycles more than its own 8 (tools/microbench10/11.hip: 8 exps + 88 FMAs take 357 cycles per group per
+// SIMD issued back to back, 302 with one wait state -- or any scalar instruction -- after each exp; the parts alone sum to 278).
+// Issuing the instruction from here with its wait state attached keeps the pair together through scheduling.  Same
+// instruction, same result bits as __builtin_amdgcn_exp2f.  Used by the bilateral kernels (measured +3.5 %, 0.163 vs 0.169 ms
+// per 1080p frame at r = 8); the NLM loop keeps the builtin (there it measured -2 % / -6 %, see csrc/nlm.hip).
+#ifndef MID_EXP_NOP
+#define MID_EXP_NOP 1
+#endif
+__device__ __forceinline__ float exp2_hw(float x)
+{
+#if MID_EXP_NOP == 1
+    float r;
+    asm("v_exp_f32_e32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(x));
+    return r;
+#elif MID_EXP_NOP == 2      /* A/B builds: the instruction from inline asm WITHOUT a wait state; with two */
+    float r;
+    asm("v_exp_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#elif MID_EXP_NOP == 3
+    float r;
+    asm("v_exp_f32_e32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return __builtin_amdgcn_exp2f(x);
+#endif
+}
 // Whole-wave lane shifts through DPP (no LDS traffic): value of lane l-1 / l+1; lanes without
 // a source read 0.
 __device__ __forceinline__ float wave_shr1(float v)   // result[l] = v[l-1]

@@ -190,6 +190,9 @@ void nlm_strip_kernel(const NlmArgs a)
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const float d = horizontal_box<PLO, PHI>(V[k]);
+                // (the builtin, not common.hpp's exp2_hw: in THIS loop a wait state after each v_exp_f32 measured 2 % slower as
+                // a block of eight and 6 % slower exp by exp, DESIGN.md 3.1 -- the weights feed dependent FMAs at once and the
+                // other wave of the SIMD fills the gaps)
                 const float wt = __builtin_amdgcn_exp2f(-d);           // exp(-d/h^2), nonlocal.comp:55 (d carries log2(e)/h^2)
                 const float4 c = n[k + NL];                             // centre texel Nb(p+s) of output row k
                 acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);   // :56

@@ -19,6 +19,12 @@
 #include "common.hpp"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
+
+#ifndef MID_NLM_PRIO_PHASES
+#define MID_NLM_PRIO_PHASES 1111 /* issue priority of the five phases of an offset, one decimal digit each: distance, vertical sums, DPP sums,
+                                   exp, accumulate, preceded by an optional sixth digit for the issue of the next offset's tile reads; A/B builds pass other codes */
+#endif
 
 namespace mid {
 
@@ -173,7 +179,30 @@ void nlm_strip_kernel(const NlmArgs a)
         for (int k = 0; k < R; ++k) { acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); accw[k] = 0.001f; }  // nonlocal.comp:32-33
 
         // One search offset: n[m] = Nb(q + s) for the lane's DR rows -> distances -> box sums -> weights.
+        //
+        // Issue priority by phase (round 3).  The two waves of a SIMD are arbitrated by priority, then age.  Left alone, one
+        // wave's plain instructions interleave with the other wave's DPP adds and transcendentals, and such a mix costs far
+        // more than its parts: tools/microbench12.hip -- 48 DPP adds + 144 FMAs per wave take 656 cycles per group per SIMD
+        // against 548 for the two blocks alone, and 455 with s_setprio raised around the DPP block; microbench10/11 show the
+        // same for v_exp_f32.  So a wave raises its priority when it enters its DPP phase and drops it after its exps: it runs
+        // through its expensive instructions in one piece while the other wave waits its turn, and the cheap phases pair up.
+        // kPrio = priority of {distance, vertical sums, DPP sums, exp, accumulate}; scheduling barriers keep each phase in one
+        // piece where the priority changes.  Same instructions, same order of operations per value: identical output bits.
+        constexpr int kPrio[6] = {(MID_NLM_PRIO_PHASES / 10000) % 10, (MID_NLM_PRIO_PHASES / 1000) % 10, (MID_NLM_PRIO_PHASES / 100) % 10,
+                                  (MID_NLM_PRIO_PHASES / 10) % 10, MID_NLM_PRIO_PHASES % 10,
+                                  (MID_NLM_PRIO_PHASES / 100000) % 10};      // [5]: while the next offset's tile reads are issued
+        auto phase = [&](auto from, auto to) {      // compile-time phase indices
+            constexpr int a = kPrio[decltype(from)::value], b = kPrio[decltype(to)::value];
+            if constexpr (a != b) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(b);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>; using P2 = std::integral_constant<int, 2>;
+        using P3 = std::integral_constant<int, 3>; using P4 = std::integral_constant<int, 4>; using PL = std::integral_constant<int, 5>;
         auto compute = [&](const float4 (&n)[DR]) {
+            phase(PL{}, P0{});
             float D[DR];
 #pragma unroll
             for (int m = 0; m < DR; ++m) {
@@ -185,15 +214,22 @@ void nlm_strip_kernel(const NlmArgs a)
 #endif
                 D[m] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
             }
+            phase(P0{}, P1{});
             float V[R];
             vertical_box<PW, R>(D, V);
+            phase(P1{}, P2{});
+            float dd[R], ww[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) dd[k] = horizontal_box<PLO, PHI>(V[k]);
+            phase(P2{}, P3{});
+            // (the builtin, not common.hpp's exp2_hw: in THIS loop a wait state after each v_exp_f32 measured 2 % slower as a
+            // block of eight and 6 % slower exp by exp)
+#pragma unroll
+            for (int k = 0; k < R; ++k) ww[k] = __builtin_amdgcn_exp2f(-dd[k]);    // exp(-d/h^2), nonlocal.comp:55 (d carries log2(e)/h^2)
+            phase(P3{}, P4{});
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const float d = horizontal_box<PLO, PHI>(V[k]);
-                // (the builtin, not common.hpp's exp2_hw: in THIS loop a wait state after each v_exp_f32 measured 2 % slower as
-                // a block of eight and 6 % slower exp by exp, DESIGN.md 3.1 -- the weights feed dependent FMAs at once and the
-                // other wave of the SIMD fills the gaps)
-                const float wt = __builtin_amdgcn_exp2f(-d);           // exp(-d/h^2), nonlocal.comp:55 (d carries log2(e)/h^2)
+                const float wt = ww[k];
                 const float4 c = n[k + NL];                             // centre texel Nb(p+s) of output row k
                 acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);   // :56
                 acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
@@ -206,6 +242,7 @@ void nlm_strip_kernel(const NlmArgs a)
 #pragma unroll
             for (int m = 0; m < DR; ++m)
                 if (m < NL || m >= NL + R) asm volatile("" ::"v"(n[m].w), "v"(accw[R - 1]));
+            phase(P4{}, PL{});
         };
         auto load = [&](float4 (&n)[DR], const float4 *p) {
 #pragma unroll

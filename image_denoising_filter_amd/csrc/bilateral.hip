@@ -18,6 +18,13 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef MID_BIL_PRIO_ACC
+#define MID_BIL_PRIO_ACC 1   /* 1: the raised priority also covers the group's accumulates */
+#endif
+#ifndef MID_BIL_GROUP
+#define MID_BIL_GROUP 2      /* tile rows per exp burst of the tiled kernel (0 = tap by tap, the round-2 loop); A/B: tools/ab_bil_libs.py */
+#endif
+
 namespace mid {
 
 struct BilArgs {
@@ -118,6 +125,67 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
 #pragma unroll
             for (int j = 0; j <= R; ++j) sij[j] = si + sj[j];
             const int base = (wv * P) * LW + lane + R + i;
+#if MID_BIL_GROUP > 0
+            // Rows in groups of MID_BIL_GROUP: exponent arguments of the group (plain VALU), then ALL its v_exp_f32 in one burst at
+            // raised issue priority, then the accumulates.  A transcendental mixed into other waves' plain instructions costs
+            // far more than its own 8 cycles (tools/microbench10/11.hip: 8 exps + 88 FMAs 357 cycles per group per SIMD against
+            // 67 + 211 alone; 274 with s_setprio around the exp burst); scheduling barriers keep the three phases apart.
+            // Same instructions per tap, same accumulation order: identical output bits.
+            constexpr int RG = MID_BIL_GROUP;
+#pragma unroll
+            for (int m0 = 0; m0 < MR; m0 += RG) {
+                float4 cc[RG];
+                float ar[RG][P];
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const int m = m0 + r;
+                    if (m >= MR) continue;
+                    const float4 g = gde_t[base + m * LW];
+                    cc[r] = g;
+                    if (MODE != 0) cc[r] = img_t[base + m * LW];
+#pragma unroll
+                    for (int k = 0; k < P; ++k) {
+                        const int j = m - R - k;
+                        if (j < -R || j > R) continue;
+                        const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
+                        ar[r][k] = fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, sij[j < 0 ? -j : j])));
+                    }
+                    if (MODE != 0) asm volatile("" ::"v"(g.w), "v"(accw[P - 1]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int r = 0; r < RG; ++r)
+#pragma unroll
+                    for (int k = 0; k < P; ++k) {
+                        const int j = m0 + r - R - k;
+                        if (m0 + r >= MR || j < -R || j > R) continue;
+                        ar[r][k] = __builtin_amdgcn_exp2f(ar[r][k]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#if !MID_BIL_PRIO_ACC
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                for (int r = 0; r < RG; ++r)
+#pragma unroll
+                    for (int k = 0; k < P; ++k) {
+                        const int j = m0 + r - R - k;
+                        if (m0 + r >= MR || j < -R || j > R) continue;
+                        const float wt = ar[r][k];
+                        const float4 c = cc[r];
+                        acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
+                        acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
+                        accw[k] += wt;
+                    }
+#if MID_BIL_PRIO_ACC
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+#else
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
                 // keep the compiler from hoisting every row's LDS read to the top of the
@@ -141,6 +209,7 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
                 // ds_read_b128 (4 LDS cycles) instead of being narrowed to ds_read_b96 (8)
                 if (MODE != 0) asm volatile("" ::"v"(g.w), "v"(accw[P - 1]));
             }
+#endif
         }
 #pragma unroll
         for (int k = 0; k < P; ++k) {

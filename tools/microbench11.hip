@@ -55,6 +55,9 @@ PROBE(k_m2, MIXN(2))
 PROBE(k_bs, EXS(90) EXS(91) EXS(92) EXS(93) EXS(94) EXS(95) EXS(96) EXS(97) ALLF)
 #define EXF(a, f) "v_exp_f32 v" #a ", v81\n" F(f)
 PROBE(k_alt, EXF(90, 100) EXF(91, 101) EXF(92, 102) EXF(93, 103) EXF(94, 104) EXF(95, 105) EXF(96, 106) EXF(97, 107) G(1) G(2) G(3) G(4) G(5) G(6) G(7) F(108) F(109) F(100))
+PROBE(k_bp, "s_setprio 1\n" EX0(90) EX0(91) EX0(92) EX0(93) EX0(94) EX0(95) EX0(96) EX0(97) "s_setprio 0\n" ALLF)
+PROBE(k_bpn, "s_setprio 1\n" EXN(90, 0) EXN(91, 0) EXN(92, 0) EXN(93, 0) EXN(94, 0) EXN(95, 0) EXN(96, 0) EXN(97, 0) "s_setprio 0\n" ALLF)
+PROBE(k_bpf, EX0(90) EX0(91) EX0(92) EX0(93) EX0(94) EX0(95) EX0(96) EX0(97) "s_setprio 1\n" ALLF "s_setprio 0\n")
 PROBE(k_f, ALLF)
 
 template <typename K>
@@ -91,6 +94,8 @@ int main()
     run("interleaved, s_nop 15 after each exp", k_m15);
     run("burst, s_nop 0 after each exp", k_b0n); run("burst, s_nop 2 after each exp", k_b2);
     run("interleaved, s_nop 0 after each exp", k_m0n); run("interleaved, s_nop 1 after each exp", k_m1); run("interleaved, s_nop 2 after each exp", k_m2);
+    run("burst, s_setprio 1 around the 8 exps", k_bp); run("burst, s_setprio 1 around (exp + s_nop 0) x 8", k_bpn);
+    run("burst, s_setprio 1 around the 88 fma", k_bpf);
     run("burst, two s_mov after each exp", k_bs); run("exp,fma alternating x8, then 80 fma", k_alt);
     return 0;
 }

@@ -308,8 +308,10 @@ void nlm_strip_kernel(const NlmArgs a)
                     __builtin_amdgcn_sched_barrier(0);
                     load_rows(hl, c1, ptr_of(o + 1));
                     __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
                     finish(D, c0);
                     __builtin_amdgcn_sched_barrier(0);      // (or the next offset's distance phase is hoisted up to the reads just issued)
+                    __builtin_amdgcn_s_setprio(0);
                 }
                 {
                     float D[DR];
@@ -317,8 +319,10 @@ void nlm_strip_kernel(const NlmArgs a)
                     __builtin_amdgcn_sched_barrier(0);
                     load_rows(hl, c0, ptr_of(o + 2 < n_off ? o + 2 : n_off - 1));
                     __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
                     finish(D, c1);
                     __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(0);
                 }
             }
             if (n_off & 1) {

@@ -21,6 +21,9 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef MID_NLM_DIST_SPLIT
+#define MID_NLM_DIST_SPLIT 0
+#endif
 #ifndef MID_NLM_PRIO_PHASES
 #define MID_NLM_PRIO_PHASES 1111 /* issue priority of the five phases of an offset, one decimal digit each: distance, vertical sums, DPP sums,
                                    exp, accumulate, preceded by an optional sixth digit for the issue of the next offset's tile reads; A/B builds pass other codes */
@@ -206,6 +209,9 @@ void nlm_strip_kernel(const NlmArgs a)
             float D[DR];
 #pragma unroll
             for (int m = 0; m < DR; ++m) {
+#if MID_NLM_DIST_SPLIT > 0      /* A/B builds: the last rows of the distance phase already at the next phase's priority */
+                if (m == MID_NLM_DIST_SPLIT) phase(P0{}, P1{});
+#endif
 #ifdef MID_NLM_PKD
                 const v2f d2 = Trg[m] - v2f{n[m].x, n[m].y};
                 const float dx = d2.x, dy = d2.y, dz = Tb[m] - n[m].z;
@@ -214,7 +220,9 @@ void nlm_strip_kernel(const NlmArgs a)
 #endif
                 D[m] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
             }
+#if !(MID_NLM_DIST_SPLIT > 0)
             phase(P0{}, P1{});
+#endif
             float V[R];
             vertical_box<PW, R>(D, V);
             phase(P1{}, P2{});

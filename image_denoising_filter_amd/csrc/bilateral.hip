@@ -416,7 +416,11 @@ static int dispatch_radius(mid_ctx *ctx, int radius, BilArgs &a, hipStream_t s, 
     // independent waves (P = 2 rows per lane, 8 waves per workgroup) beat deeper register blocking.
     switch (radius) {
     case 4:  return launch_tiled<4, 2, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);    // BASELINE config 1 window
-    case 8:  return launch_tiled<8, 2, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);    // BASELINE configs 2 and 4
+#ifndef MID_BIL_R8_P
+#define MID_BIL_R8_P 2
+#define MID_BIL_R8_NW 8
+#endif
+    case 8:  return launch_tiled<8, MID_BIL_R8_P, MID_BIL_R8_NW, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);    // BASELINE configs 2 and 4 (shape: A/B builds pass -DMID_BIL_R8_P/-DMID_BIL_R8_NW)
     case 10: return launch_tiled<10, 2, 16, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);  // CPU path window, src/main.cpp:1819
     case 20:                                                                 // TEXEL_WINDOW as shipped
         return launch_tiled<20, 1, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);          // 80 KB tile: two workgroups per CU (or image + guide tile)

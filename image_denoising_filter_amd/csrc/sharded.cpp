@@ -330,7 +330,13 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
 
     // receive buffers (kept across calls; a call's receives are ordered after the previous call's last readers through
     // e0: calls on one communicator must be issued on one stream, or be separated by a synchronisation)
-    if (frame_bytes > c->halo_bytes) { for (void *q : c->halo) (void)hipFree(q); c->halo.clear(); c->halo_bytes = frame_bytes; }
+    if (frame_bytes > c->halo_bytes) {
+        // (rare: the frame size grew between calls.  The old buffers may still be read by launches of the previous call.)
+        if (!c->halo.empty()) MID_HIP(hipDeviceSynchronize());
+        for (void *q : c->halo) (void)hipFree(q);
+        c->halo.clear();
+        c->halo_bytes = frame_bytes;
+    }
     while (c->halo.size() < rv.size()) { void *q = nullptr; MID_HIP(hipMalloc(&q, c->halo_bytes)); c->halo.push_back(q); }
 
     if (!rv.empty() || !sd.empty()) {

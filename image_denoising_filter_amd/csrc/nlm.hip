@@ -21,6 +21,12 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef MID_NLM_SINGLE_SYP
+#define MID_NLM_SINGLE_SYP 3     /* search rows per tile fill of the single-frame launches (0 = the single-pass tile for every launch size) */
+#endif
+#ifndef MID_NLM_SINGLE_SYP_REF
+#define MID_NLM_SINGLE_SYP_REF 7 /* the same for the reference's shipped windows: 77 x 43 texels, two fills */
+#endif
 #ifndef MID_NLM_DIST_SPLIT
 #define MID_NLM_DIST_SPLIT 0
 #endif
@@ -596,10 +602,21 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
         }
 #endif
         if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3>(ctx, a, s);
+#if MID_NLM_SINGLE_SYP > 0
+        // A launch over ONE frame (the frame pipeline's launches, mid_nlm_accum, latency-bound callers) is 1156 workgroups: on
+        // the 512 slots of the 76 KB single-pass tile that is 2.26 rounds, the last one a quarter full.  The multi-pass tile
+        // (52.5 KB, three workgroups per CU, 768 slots: 1.5 rounds) walks the same offsets in the same order -- identical
+        // output bits (tested) -- and finishes a lone frame 10 % sooner; over many frames the single-pass tile is as fast or
+        // faster, so the choice goes by launch size.
+        if (a.count == 1) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3, false, MID_NLM_SINGLE_SYP>(ctx, a, s);
+#endif
         return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s);
     }
     if (p->search_lo == -7 && p->search_hi == 7 && p->patch_lo == -3 && p->patch_hi == 3) {     // nonlocal.comp:5-6 as shipped
         if (multi) return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, FUSED, 2>(ctx, a, s);
+#if MID_NLM_SINGLE_SYP_REF > 0
+        if (a.count == 1) return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2, false, MID_NLM_SINGLE_SYP_REF>(ctx, a, s);   // 77 x 43 texels = 51.7 KB: three workgroups per CU
+#endif
         return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2>(ctx, a, s);
     }
     // Any other search window with one of the common patches: the same strip kernel with the search

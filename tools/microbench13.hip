@@ -74,6 +74,12 @@ PROBE(k_pf2, WAIT F84 P(1) L14NW F18 D48 E8 F40 P(0))           // ... issued in
 PROBE(k_pf3, WAIT F84 P(1) F18 D48 L14NW E8 F40 P(0))           // ... after the DPP adds
 PROBE(k_w1, L14 P(1) F84 F18 D48 E8 F40 P(0))                   // only the reads and their wait at low priority
 PROBE(k_w2, P(1) L14NW P(0) WAIT P(1) F84 F18 D48 E8 F40 P(0))  // reads issued at raised priority, only the wait low
+#define L6NW "ds_read_b128 v[20:23], v82\n ds_read_b128 v[24:27], v82 offset:1344\n ds_read_b128 v[28:31], v82 offset:2688\n" \
+             "ds_read_b128 v[64:67], v82 offset:14784\n ds_read_b128 v[68:71], v82 offset:16128\n ds_read_b128 v[72:75], v82 offset:17472\n"
+#define L8NW "ds_read_b128 v[32:35], v82 offset:4032\n ds_read_b128 v[36:39], v82 offset:5376\n ds_read_b128 v[40:43], v82 offset:6720\n ds_read_b128 v[44:47], v82 offset:8064\n" \
+             "ds_read_b128 v[48:51], v82 offset:9408\n ds_read_b128 v[52:55], v82 offset:10752\n ds_read_b128 v[56:59], v82 offset:12096\n ds_read_b128 v[60:63], v82 offset:13440\n"
+PROBE(k_pp, WAIT F84 L6NW P(1) F18 D48 E8 F40 P(0) L8NW)        // partial prefetch: the 6 halo rows after the distance phase, the 8 centre rows after the accumulate (no extra registers)
+PROBE(k_pp2, WAIT F84 P(1) L6NW F18 D48 E8 F40 L8NW P(0))
 PROBE(k_c1111b, L14 F84 P(1) F18 D48 E8 F40 P(0) "s_nop 0\n")
 
 template <typename K>
@@ -108,7 +114,8 @@ int main()
     run("[48 dpp, 8 exp][142 fma], no priorities", k_a0); run("[48 dpp, 8 exp]@1 [142 fma]@0", k_a1);
     run("[48 dpp, 8 exp]@1 [14 reads + wait, 142 fma]@0", k_b1);
     run("prefetch: reads after the distance phase, 01111", k_pf1); run("prefetch: reads first thing in the raised block", k_pf2);
-    run("prefetch: reads after the DPP adds", k_pf3); run("only reads + wait low, everything else raised", k_w1);
+    run("prefetch: reads after the DPP adds", k_pf3); run("partial prefetch: halo rows early, centre rows late", k_pp); run("partial prefetch, both issued at raised priority", k_pp2);
+    run("only reads + wait low, everything else raised", k_w1);
     run("reads issued raised, only the wait low", k_w2);
     run("kernel order, no priorities", k_c0); run("kernel order, 00110", k_c110); run("kernel order, 01111", k_c1111);
     return 0;

@@ -20,12 +20,16 @@
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
+#ifndef MID_NLM_WALK
+#define MID_NLM_WALK 21          /* search rows walked innermost in runs of this many (0 = search column innermost, the round-1/2 order) */
+#endif
 #ifndef MID_NLM_SINGLE_SYP
-#define MID_NLM_SINGLE_SYP 3     /* search rows per tile fill of the single-frame launches (0 = the single-pass tile for every launch size) */
+#define MID_NLM_SINGLE_SYP 0     /* search rows per tile fill of the single-frame launches (0 = the single-pass tile for every launch size); must equal MID_NLM_WALK when both are set */
 #endif
 #ifndef MID_NLM_SINGLE_SYP_REF
-#define MID_NLM_SINGLE_SYP_REF 7 /* the same for the reference's shipped windows: 77 x 43 texels, two fills */
+#define MID_NLM_SINGLE_SYP_REF 0 /* the same for the reference's shipped windows */
 #endif
 #ifndef MID_NLM_DIST_SPLIT
 #define MID_NLM_DIST_SPLIT 0
@@ -409,6 +413,81 @@ void nlm_strip_kernel(const NlmArgs a)
                     compute_sym(n, M, Mw);
                 }
                 fold(M, Mw);
+            }
+        } else if constexpr (MID_NLM_WALK > 0) {
+            // Search rows walked INNERMOST in runs of MID_NLM_WALK (round 3).  Two offsets that differ by one search row read 13
+            // of the same 14 tile rows (the lane's column, rows sy..sy+13 against sy+1..sy+14), so within a run only ONE new row
+            // is read per offset -- into the register slot of the row that has just left the window, right after the distance
+            // phase has used it for the last time -- instead of all 14: (14 + W - 1) / W tile reads per offset.  The register
+            // window is a ring indexed at compile time (the run is fully unrolled).  The order of the offsets -- runs of W
+            // search rows; inside a run search column outer, row inner -- is the same in the single-pass and in the multi-pass
+            // tile (whose passes are the runs), so the two still give identical bits; it differs from rounds 1-2 (and from the
+            // shader's y-outer loop, nonlocal.comp:36-38) in the order the 441 non-negative terms are added.
+            constexpr int WALK = (!RTS && SHI - SLO < MID_NLM_WALK) ? SHI - SLO : MID_NLM_WALK;   // (a tuned window narrower than the run: one run per search column)
+            static_assert(SYP == 0 || SYP == WALK, "the multi-pass tile's passes are the runs of the walk");
+            static_assert(NL >= 1, "the row that leaves the window must not be a centre row");
+            // one offset of a run: window row r lives in register slot (j + r) % DR
+            auto step = [&](int j, float4 (&n)[DR], const float4 *nextp, bool more) {
+                phase(PL{}, P0{});
+                float D[DR];
+#pragma unroll
+                for (int m = 0; m < DR; ++m) {
+                    const float4 &t = n[(j + m) % DR];
+                    const float dx = Tr[m] - t.x, dy = Tg[m] - t.y, dz = Tb[m] - t.z;
+                    D[m] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                }
+                // the row that leaves the window: its alpha was never used unless it has been a centre row; keep it formally
+                // live up to here so that every tile read stays a ds_read_b128, then reuse its slot for the row that enters
+                asm volatile("" ::"v"(n[j % DR].w));
+                if (more) n[j % DR] = nextp[0];
+                phase(P0{}, P1{});
+                float V[R];
+                vertical_box<PW, R>(D, V);
+                phase(P1{}, P2{});
+                float dd[R], ww[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) dd[k] = horizontal_box<PLO, PHI>(V[k]);
+                phase(P2{}, P3{});
+#pragma unroll
+                for (int k = 0; k < R; ++k) ww[k] = __builtin_amdgcn_exp2f(-dd[k]);
+                phase(P3{}, P4{});
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const float wt = ww[k];
+                    const float4 c = n[(j + k + NL) % DR];            // centre texel of output row k = window row k + NL
+                    acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
+                    acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
+                    accw[k] += wt;
+                }
+                phase(P4{}, PL{});
+            };
+            // `steps` <= WALK consecutive search rows at one search column; FULL: steps == WALK is known at compile time
+            auto run = [&](const bool FULL, const float4 *colp, int steps) __attribute__((always_inline)) {
+                float4 n[DR];
+#pragma unroll
+                for (int m = 0; m < DR; ++m) n[m] = colp[m * LW];
+#pragma unroll
+                for (int j = 0; j < WALK; ++j) {
+                    if (FULL || j < steps) step(j, n, colp + (DR + j) * LW, FULL ? j + 1 < WALK : j + 1 < steps);
+                }
+                // rows still in the window that never were centre rows: keep their alpha formally live (see above)
+#pragma unroll
+                for (int m = 0; m < DR; ++m) asm volatile("" ::"v"(n[m].w), "v"(accw[R - 1]));
+            };
+            for (int sy0 = 0; sy0 < SW; sy0 += WALK) {
+                if constexpr (SYP > 0) {
+                    if (sy0 > 0) {
+                        __syncthreads();
+                        fill_tile<FMT, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo + sy0, tid, NW * 64, a.sk);
+                        __syncthreads();
+                    }
+                }
+                if (wave_active) {
+                    const int steps = sy0 + WALK < SW ? WALK : SW - sy0;
+                    const float4 *rowp = lds + (wv * R + (SYP > 0 ? 0 : sy0)) * LW + lane;
+                    if (steps == WALK) { for (int sx = 0; sx < SW; ++sx) run(true, rowp + sx, steps); }
+                    else { for (int sx = 0; sx < SW; ++sx) run(false, rowp + sx, steps); }
+                }
             }
         } else if constexpr (SYP > 0) {
             for (int sy0 = 0; sy0 < SW; sy0 += SYP) {          // one tile fill per SYP search rows; same offset order as the single pass

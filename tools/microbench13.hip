@@ -80,6 +80,14 @@ PROBE(k_w2, P(1) L14NW P(0) WAIT P(1) F84 F18 D48 E8 F40 P(0))  // reads issued 
              "ds_read_b128 v[48:51], v82 offset:9408\n ds_read_b128 v[52:55], v82 offset:10752\n ds_read_b128 v[56:59], v82 offset:12096\n ds_read_b128 v[60:63], v82 offset:13440\n"
 PROBE(k_pp, WAIT F84 L6NW P(1) F18 D48 E8 F40 P(0) L8NW)        // partial prefetch: the 6 halo rows after the distance phase, the 8 centre rows after the accumulate (no extra registers)
 PROBE(k_pp2, WAIT F84 P(1) L6NW F18 D48 E8 F40 L8NW P(0))
+#define L1W "ds_read_b128 v[20:23], v82\n s_waitcnt lgkmcnt(0)\n"
+#define L2W "ds_read_b128 v[20:23], v82\n ds_read_b128 v[24:27], v82 offset:1344\n s_waitcnt lgkmcnt(0)\n"
+#define L5W "ds_read_b128 v[20:23], v82\n ds_read_b128 v[24:27], v82 offset:1344\n ds_read_b128 v[28:31], v82 offset:2688\n ds_read_b128 v[32:35], v82 offset:4032\n ds_read_b128 v[36:39], v82 offset:5376\n s_waitcnt lgkmcnt(0)\n"
+#define L3W "ds_read_b128 v[20:23], v82\n ds_read_b128 v[24:27], v82 offset:1344\n ds_read_b128 v[28:31], v82 offset:2688\n s_waitcnt lgkmcnt(0)\n"
+PROBE(k_l1, L1W F84 P(1) F18 D48 E8 F40 P(0))                   // kernel order 01111 with ONE tile read per offset (search rows walked innermost: 13 of the 14 rows stay in registers)
+PROBE(k_l2, L2W F84 P(1) F18 D48 E8 F40 P(0))
+PROBE(k_l3, L3W F84 P(1) F18 D48 E8 F40 P(0))
+PROBE(k_l5, L5W F84 P(1) F18 D48 E8 F40 P(0))
 PROBE(k_c1111b, L14 F84 P(1) F18 D48 E8 F40 P(0) "s_nop 0\n")
 
 template <typename K>
@@ -117,6 +125,7 @@ int main()
     run("prefetch: reads after the DPP adds", k_pf3); run("partial prefetch: halo rows early, centre rows late", k_pp); run("partial prefetch, both issued at raised priority", k_pp2);
     run("only reads + wait low, everything else raised", k_w1);
     run("reads issued raised, only the wait low", k_w2);
+    run("kernel order 01111, 1 read per offset", k_l1); run("kernel order 01111, 2 reads per offset", k_l2); run("kernel order 01111, 3 reads per offset", k_l3); run("kernel order 01111, 5 reads per offset", k_l5);
     run("kernel order, no priorities", k_c0); run("kernel order, 00110", k_c110); run("kernel order, 01111", k_c1111);
     return 0;
 }

@@ -414,7 +414,7 @@ void nlm_strip_kernel(const NlmArgs a)
                 }
                 fold(M, Mw);
             }
-        } else if constexpr (MID_NLM_WALK > 0) {
+        } else if constexpr (MID_NLM_WALK > 0 && (SYP == 0 || SYP == MID_NLM_WALK)) {   // (tuning variants with other pass sizes keep the old loop below)
             // Search rows walked INNERMOST in runs of MID_NLM_WALK (round 3).  Two offsets that differ by one search row read 13
             // of the same 14 tile rows (the lane's column, rows sy..sy+13 against sy+1..sy+14), so within a run only ONE new row
             // is read per offset -- into the register slot of the row that has just left the window, right after the distance

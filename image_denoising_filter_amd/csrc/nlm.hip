@@ -8,12 +8,19 @@
 //   * a wave owns 64 adjacent columns x R rows; lane l owns one column, keeps its target
 //     column strip T(q) in VGPRs for the whole kernel and reads Nb(q+s) from an LDS tile
 //     (float4 per texel: one conflict-free ds_read_b128 per texel);
+//   * the offsets are walked search row INNERMOST (MID_NLM_WALK): two offsets one search row apart share 13 of their
+//     14 tile rows, which stay in a compile-time-indexed ring of registers -- 1.6 tile reads per offset instead of 14;
+//   * each offset runs as phases -- distances | vertical sums | DPP sums | exps | accumulate -- and the wave raises its
+//     issue priority (s_setprio) from the vertical sums on: on gfx950 a mix of one wave's plain instructions with the
+//     other wave's DPP adds / transcendentals costs far more than its parts unless the DPP/exp wave has priority
+//     (tools/microbench10-13.hip);
 //   * the vertical PW-tap sums are formed in registers by block prefix/suffix sums (18 adds per 8 outputs);
 //   * the horizontal PW-tap sums move across lanes with whole-wave DPP shifts fused into
 //     v_add_f32 (no LDS traffic, no shuffles): 64-(PW-1) lanes hold finished patch distances;
 //   * v_exp_f32 with the -log2(e)/h^2 factor folded in, then 4 FMAs + 1 add per (pixel,offset).
 // All sums are of non-negative terms (no running-sum cancellation), so results agree with
-// the reference order to a few ulp of the patch distance.
+// the reference order to a few ulp of the patch distance; the per-pixel sum over the offsets is taken column-outer /
+// row-inner, not in the shader's y-outer order (same terms, different last bits; one order for every launch shape).
 //
 // Out-of-image texels are vec4(0) for both images (LDS halo zero-filled).
 #include "common.hpp"

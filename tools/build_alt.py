@@ -13,8 +13,9 @@ name, src_rel, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
 ALL = "capi.cpp pointwise.hip bilateral.hip nlm.hip pipeline.cpp sharded.cpp codec/png.cpp codec/exr.cpp codec/piz.cpp codec/image_capi.cpp".split()
 assert src_rel in ALL, src_rel
 base = "-x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function".split()
-if src_rel == "nlm.hip":
+if src_rel == "nlm.hip" and "--default-sched" not in extra:
     base += ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+extra = [e for e in extra if e != "--default-sched"]
 d = os.path.join(ROOT, "build", "abl")
 os.makedirs(d, exist_ok=True)
 o = os.path.join(d, f"{name}_{src_rel.replace('/', '_')}.o")

@@ -298,20 +298,40 @@ __global__ __launch_bounds__(512) void bilateral_rt_kernel(const BilArgs a, cons
         for (int i = -R; i <= R; ++i) {
             const float si = a.ks * (float)(i * i);
             const int base = (wv * P) * LW + lane + R + i;
-            for (int m = 0; m < P + 2 * R; ++m) {
+            // Tile row m feeds output k = 0 with row offset j = m - R and output k = 1 with j = m - R - 1; the first row has only the
+            // k = 0 tap, the last only the k = 1 tap, and the 2R rows between them go in PAIRS with their four exps as one burst at
+            // raised issue priority, like the tuned kernel (MID_BIL_GROUP; per output the taps are still added in row order: same bits).
+            auto arg_of = [&](const float4 &g, int k, int j) {
+                const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
+                return fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, fmaf(a.ks, (float)(j * j), si))));
+            };
+            auto add_tap = [&](const float4 &c, int k, float wt) {
+                acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
+                acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
+                accw[k] += wt;
+            };
+            {
+                const float4 g = gde_t[base];
+                add_tap(MODE != 0 ? img_t[base] : g, 0, exp2_hw(arg_of(g, 0, -R)));
+            }
+            for (int m = 1; m < 2 * R; m += 2) {
+                const float4 g0 = gde_t[base + m * LW], g1 = gde_t[base + (m + 1) * LW];
+                const float4 c0 = MODE != 0 ? img_t[base + m * LW] : g0, c1 = MODE != 0 ? img_t[base + (m + 1) * LW] : g1;
+                float w00 = arg_of(g0, 0, m - R), w01 = arg_of(g0, 1, m - R - 1), w10 = arg_of(g1, 0, m + 1 - R), w11 = arg_of(g1, 1, m - R);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                w00 = __builtin_amdgcn_exp2f(w00); w01 = __builtin_amdgcn_exp2f(w01);
+                w10 = __builtin_amdgcn_exp2f(w10); w11 = __builtin_amdgcn_exp2f(w11);
+                __builtin_amdgcn_sched_barrier(0);
+                add_tap(c0, 0, w00); add_tap(c0, 1, w01); add_tap(c1, 0, w10); add_tap(c1, 1, w11);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                const int m = 2 * R + 1;
                 const float4 g = gde_t[base + m * LW];
-                float4 c = g;
-                if (MODE != 0) c = img_t[base + m * LW];
-#pragma unroll
-                for (int k = 0; k < P; ++k) {
-                    const int j = m - R - k;
-                    if (j < -R || j > R) continue;               // wave-uniform
-                    const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
-                    const float wt = exp2_hw(fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, fmaf(a.ks, (float)(j * j), si)))));
-                    acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
-                    acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
-                    accw[k] += wt;
-                }
+                add_tap(MODE != 0 ? img_t[base + m * LW] : g, 1, exp2_hw(arg_of(g, 1, R)));
             }
         }
 #pragma unroll

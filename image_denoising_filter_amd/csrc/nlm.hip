@@ -717,6 +717,7 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
             return launch_strip<0, 0, PLO_, PHI_, 8, 4, FMT, FUSED, false, 1>(ctx, a, s);                       \
         }
         MID_NLM_RT(-3, 4) MID_NLM_RT(-3, 3) MID_NLM_RT(-2, 3) MID_NLM_RT(-1, 2) MID_NLM_RT(-4, 5)
+        MID_NLM_RT(-2, 2) MID_NLM_RT(-4, 4)      // 4x4 and 8x8: the reference's half-open style ([-P,P), shaders/nonlocal.comp:42-44) at other sizes
 #undef MID_NLM_RT
     }
     dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16), FUSED ? a.count : 1);

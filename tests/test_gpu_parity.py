@@ -91,7 +91,8 @@ NLM_CFGS = {"ref": dict(search=(-7, 7), patch=(-3, 3)), "bench": dict(search=(-1
             "generic": dict(search=(-3, 4), patch=(-1, 2)),           # run-time search range, 3x3 patch
             "rt7": dict(search=(-6, 9), patch=(-3, 4)),               # run-time (asymmetric) search, 7x7 patch
             "rt5": dict(search=(-12, 13), patch=(-2, 3)),             # 25x25 search, 5x5 patch
-            "naive": dict(search=(-2, 3), patch=(-2, 2))}             # 4x4 patch: one-thread-per-pixel fallback
+            "rt4": dict(search=(-4, 5), patch=(-2, 2)),               # 4x4 patch ([-P,P) at P=2) on the strip kernel
+            "naive": dict(search=(-2, 3), patch=(-1, 1))}             # 2x2 patch: no strip instantiation -> one-thread-per-pixel fallback
 
 
 def _nlm_pair(rng, h, w, scale=0.25):
@@ -100,7 +101,7 @@ def _nlm_pair(rng, h, w, scale=0.25):
     return t, nb
 
 
-@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "naive"])
+@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "rt4", "naive"])
 def test_nlm_accum(ctx, cfg):
     rng = np.random.default_rng(40)
     h, w = 71, 125                                   # > 1 tile in x (58/59 px) and y (64 px), ragged
@@ -141,7 +142,7 @@ def test_nlm_ldr_input(ctx):
     assert rel_err(ctx.nlm_accum(a, b, Z(37, 64), 0.5)[..., :5], ref[..., :5]) < NLM_TOL
 
 
-@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "naive"])
+@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt4", "naive"])
 def test_nlm_temporal_fused_equals_dispatch_sequence(ctx, cfg):
     """mid_nlm_temporal(k) == for each neighbour frame: mid_nlm_accum; then mid_normalize -- bit for
     bit -- and both match the oracle; windows clip at the sequence ends (5 frames, k=2)."""

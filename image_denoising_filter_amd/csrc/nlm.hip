@@ -29,6 +29,9 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef MID_NLM_MIN_WAVES
+#define MID_NLM_MIN_WAVES 0      /* waves per SIMD the register allocator must leave room for: 0 = per instantiation (nlm_min_waves below), 1 / 2 = A/B builds */
+#endif
 #ifndef MID_NLM_WALK
 #define MID_NLM_WALK 21          /* search rows walked innermost in runs of this many (0 = search column innermost, the round-1/2 order) */
 #endif
@@ -121,8 +124,19 @@ __device__ __forceinline__ float horizontal_box(float v)
 // so THREE workgroups share a CU (3 waves per SIMD instead of 2; the kernel needs 166 VGPRs when asked to, no spill).  The
 // offsets are visited in the same order (search row outer, search column inner), so the sums -- and the output bits --
 // are those of the single-pass kernel.
+// Waves per SIMD the register allocator must leave room for.  The LDS tile allows two, and the tuned kernels fit two without being
+// asked (183-236 VGPRs).  The run-time-window TEMPORAL kernels carry the search range in registers and the per-frame totals on top: left
+// alone, those with 4x4, 7x7, 8x8 and 9x9 patches took 256 VGPRs + 2..28 AGPRs = ONE wave per SIMD, at the single-wave issue rate
+// (half the two-wave one, tools/microbench8.hip).  Asked for two they spill 24-100 bytes per lane of cold state instead: 13x13/9x9 k=2
+// 1.41 -> 0.95 ms, 8x8/8x8 0.58 -> 0.37 ms per output frame.  The others are left unconstrained: the same request costs the 5x5-patch
+// kernel 9 % (255 -> 247 VGPRs, a tighter schedule) and the rest 2 % (profiles/r03_nlm_runtime_windows.txt).
+constexpr int nlm_min_waves(bool rts, bool multi, int pw)
+{
+    return MID_NLM_MIN_WAVES > 0 ? MID_NLM_MIN_WAVES : (rts && multi && (pw == 4 || pw >= 7)) ? 2 : 1;
+}
+
 template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0, int PF = 0>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SYP > 0 ? 3 : 1, SYP > 0 ? 3 : 2)))
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SYP > 0 ? 3 : nlm_min_waves(SLO == 0 && SHI == 0, MULTI, PHI - PLO), SYP > 0 ? 3 : 2)))
 void nlm_strip_kernel(const NlmArgs a)
 {
     // SLO == SHI == 0 selects the run-time search range [a.slo, a.shi) (any window, same patch):
@@ -711,6 +725,20 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
     {
         const int sw = p->search_hi - p->search_lo;
         auto fits = [&](int pw_) { return (size_t)(64 + sw - 1) * (32 + pw_ - 1 + sw - 1) * sizeof(float4) <= (size_t)ctx->lds_max; };
+        // Windows from 23x23 up: the 4-wave tile passes 80 KB, ONE workgroup fits a CU and its four waves have a SIMD each -- the
+        // single-wave issue rate, half the two-wave one.  An 8-wave workgroup (64 rows, one tile of up to 160 KB) brings the second
+        // wave per SIMD back: 25x25/7x7 1.22 -> 0.75 ms, 31x31/7x7 1.88 -> 1.16 ms per 1080p frame (profiles/r03_nlm_runtime_windows.txt).
+        // Strips stay 8 rows at multiples of 8: identical output bits (tested against the 4-wave shape).  Only the symmetric
+        // 3x3 / 5x5 / 7x7 patches: every instantiation costs build time.
+        auto tile_bytes = [&](int nw, int pw_) { return (size_t)(64 + sw - 1) * (nw * 8 + pw_ - 1 + sw - 1) * sizeof(float4); };
+        auto wants8 = [&](int pw_) { return 2 * tile_bytes(4, pw_) > (size_t)ctx->lds_max && tile_bytes(8, pw_) <= (size_t)ctx->lds_max; };
+#define MID_NLM_RT8(PLO_, PHI_)                                                                             \
+        if (p->patch_lo == (PLO_) && p->patch_hi == (PHI_) && wants8((PHI_) - (PLO_))) {                        \
+            if (multi) return launch_strip<0, 0, PLO_, PHI_, 8, 8, FMT, FUSED, FUSED, 1>(ctx, a, s);            \
+            return launch_strip<0, 0, PLO_, PHI_, 8, 8, FMT, FUSED, false, 1>(ctx, a, s);                       \
+        }
+        MID_NLM_RT8(-3, 4) MID_NLM_RT8(-2, 3) MID_NLM_RT8(-1, 2)
+#undef MID_NLM_RT8
 #define MID_NLM_RT(PLO_, PHI_)                                                                              \
         if (p->patch_lo == (PLO_) && p->patch_hi == (PHI_) && fits((PHI_) - (PLO_))) {                          \
             if (multi) return launch_strip<0, 0, PLO_, PHI_, 8, 4, FMT, FUSED, FUSED, 1>(ctx, a, s);            \

@@ -142,7 +142,7 @@ def test_nlm_ldr_input(ctx):
     assert rel_err(ctx.nlm_accum(a, b, Z(37, 64), 0.5)[..., :5], ref[..., :5]) < NLM_TOL
 
 
-@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt4", "naive"])
+@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "rt4", "naive"])
 def test_nlm_temporal_fused_equals_dispatch_sequence(ctx, cfg):
     """mid_nlm_temporal(k) == for each neighbour frame: mid_nlm_accum; then mid_normalize -- bit for
     bit -- and both match the oracle; windows clip at the sequence ends (5 frames, k=2)."""
@@ -375,6 +375,39 @@ def test_runtime_range_kernel_small_then_large_window(ctx):
         got = ctx.nlm_accum(t, nb, Z(40, 70), 0.5, search=search, patch=(-2, 3))
         ref = oracle.nlm_accum(t, nb, Z(40, 70), 0.5, search=search, patch=(-2, 3))
         assert rel_err(got[..., :5], ref[..., :5]) < 5e-5, search
+
+
+@pytest.mark.parametrize("search,patch", [((-12, 13), (-3, 4)), ((-15, 16), (-1, 2)), ((-11, 12), (-2, 3)), ((-17, 18), (-2, 3))])
+def test_nlm_large_window_eight_wave_workgroups(ctx, search, patch):
+    """Windows whose 4-wave tile no longer fits twice into a CU's LDS run on 8-wave workgroups (64-row tiles).  Strips
+    are still 8 rows at multiples of 8, so a pixel's bits may depend neither on the workgroup shape nor on where the
+    pixel sits in its tile: fused == accumulate + normalize, the result is invariant under a shift of the frame by 8
+    rows and 5 columns (other wave, other tile, other lane), and it matches the oracle -- on a frame taller than one
+    64-row tile, ragged in both directions."""
+    rng = np.random.default_rng(search[1] * 7 + patch[1])
+    h, w = 150, 75
+    t = (synth_hdr(rng, h, w) * 0.25).astype(np.float32)
+    fused = ctx.nlm_temporal([t], k=0, search=search, patch=patch)[0]
+    W = ctx.nlm_accum(t, t, Z(h, w), 0.5, search=search, patch=patch)
+    assert np.array_equal(fused, ctx.normalize(W))
+    ys, xs = slice(60, 90), slice(20, 60)                      # the oracle on a window across the 64-row tile seam
+    halo = -search[0] + max(-patch[0], patch[1])
+    c = np.zeros((30 + 2 * halo, 40 + 2 * halo, 4), np.float32)
+    ya, xa = ys.start - halo, xs.start - halo
+    sy, sx = slice(max(ya, 0), min(ya + c.shape[0], h)), slice(max(xa, 0), min(xa + c.shape[1], w))
+    c[sy.start - ya:sy.stop - ya, sx.start - xa:sx.stop - xa] = t[sy, sx]
+    ref = oracle.normalize(oracle.nlm_accum(c, c, Z(*c.shape[:2]), 0.5, search=search, patch=patch))[halo:halo + 30, halo:halo + 40]
+    assert rel_err(fused[ys, xs], ref) < NLM_TOL
+    shifted = ctx.nlm_temporal([np.ascontiguousarray(t[8:, 5:])], k=0, search=search, patch=patch)[0]
+    assert np.array_equal(shifted[halo:-halo, halo:-halo], fused[8 + halo:-halo, 5 + halo:-halo]), "translation by (8 rows, 5 columns)"
+    # temporal, three frames
+    frames = [t, np.roll(t, 3, axis=1), np.roll(t, -2, axis=0)]
+    fz = ctx.nlm_temporal(frames, k=1, search=search, patch=patch)
+    for i in range(3):
+        Wi = Z(h, w)
+        for f in range(max(0, i - 1), min(2, i + 1) + 1):
+            Wi = ctx.nlm_accum(frames[i], frames[f], Wi, 0.5, search=search, patch=patch)
+        assert np.array_equal(fz[i], ctx.normalize(Wi)), i
 
 
 @pytest.mark.parametrize("R", list(range(1, 25)))

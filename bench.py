@@ -501,7 +501,11 @@ def main():
     def on_timeout():
         also["error"] = "extras did not finish within 300 s; line emitted by the watchdog"
         emit()
-        os._exit(3)             # the line is out, but a run whose extras hung is not a clean run
+        # One rank: nothing below can wait for a peer, so a hang is a fault of this process -> non-zero.  N > 1: the timed
+        # region and its max-over-ranks reduction completed on every rank before any extra started; what can hang below are
+        # the halo-exchange extras, which no builder box (one GPU) could ever run on hardware.  Their failure is recorded in
+        # the line (`also.error`) and must not void the scaling measurement: exit 0 (every rank has this timer).
+        os._exit(3 if world == 1 else 0)
     watchdog = threading.Timer(300.0, on_timeout)
     watchdog.daemon = True
     watchdog.start()

@@ -446,7 +446,7 @@ void nlm_strip_kernel(const NlmArgs a)
             // shader's y-outer loop, nonlocal.comp:36-38) in the order the 441 non-negative terms are added.
             constexpr int WALK = (!RTS && SHI - SLO < MID_NLM_WALK) ? SHI - SLO : MID_NLM_WALK;   // (a tuned window narrower than the run: one run per search column)
             static_assert(SYP == 0 || SYP == WALK, "the multi-pass tile's passes are the runs of the walk");
-            static_assert(NL >= 1, "the row that leaves the window must not be a centre row");
+            constexpr bool EARLY = NL >= 1;     // the row that leaves the window is no centre row: its slot can be refilled right after the distance phase
             // one offset of a run: window row r lives in register slot (j + r) % DR
             auto step = [&](int j, float4 (&n)[DR], const float4 *nextp, bool more) {
                 phase(PL{}, P0{});
@@ -459,8 +459,10 @@ void nlm_strip_kernel(const NlmArgs a)
                 }
                 // the row that leaves the window: its alpha was never used unless it has been a centre row; keep it formally
                 // live up to here so that every tile read stays a ds_read_b128, then reuse its slot for the row that enters
-                asm volatile("" ::"v"(n[j % DR].w));
-                if (more) n[j % DR] = nextp[0];
+                if constexpr (EARLY) {
+                    asm volatile("" ::"v"(n[j % DR].w));
+                    if (more) n[j % DR] = nextp[0];
+                }
                 phase(P0{}, P1{});
                 float V[R];
                 vertical_box<PW, R>(D, V);
@@ -480,6 +482,7 @@ void nlm_strip_kernel(const NlmArgs a)
                     acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
                     accw[k] += wt;
                 }
+                if constexpr (!EARLY) { if (more) n[j % DR] = nextp[0]; }   // (patches that start at row 0: the leaving row was output row 0's centre)
                 phase(P4{}, PL{});
             };
             // `steps` <= WALK consecutive search rows at one search column; FULL: steps == WALK is known at compile time
@@ -746,6 +749,7 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
         }
         MID_NLM_RT(-3, 4) MID_NLM_RT(-3, 3) MID_NLM_RT(-2, 3) MID_NLM_RT(-1, 2) MID_NLM_RT(-4, 5)
         MID_NLM_RT(-2, 2) MID_NLM_RT(-4, 4)      // 4x4 and 8x8: the reference's half-open style ([-P,P), shaders/nonlocal.comp:42-44) at other sizes
+        MID_NLM_RT(-1, 1) MID_NLM_RT(0, 1)       // 2x2 ([-1,1)) and the pixel-wise filter (1x1 patch: no box sums left, the same loop)
 #undef MID_NLM_RT
     }
     dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16), FUSED ? a.count : 1);

@@ -92,7 +92,9 @@ NLM_CFGS = {"ref": dict(search=(-7, 7), patch=(-3, 3)), "bench": dict(search=(-1
             "rt7": dict(search=(-6, 9), patch=(-3, 4)),               # run-time (asymmetric) search, 7x7 patch
             "rt5": dict(search=(-12, 13), patch=(-2, 3)),             # 25x25 search, 5x5 patch
             "rt4": dict(search=(-4, 5), patch=(-2, 2)),               # 4x4 patch ([-P,P) at P=2) on the strip kernel
-            "naive": dict(search=(-2, 3), patch=(-1, 1))}             # 2x2 patch: no strip instantiation -> one-thread-per-pixel fallback
+            "rt2": dict(search=(-4, 5), patch=(-1, 1)),               # 2x2 patch ([-P,P) at P=1) on the strip kernel
+            "rt1": dict(search=(-6, 7), patch=(0, 1)),                # pixel-wise weights (1x1 patch) on the strip kernel
+            "naive": dict(search=(-2, 3), patch=(-5, 6))}             # 11x11 patch: no strip instantiation -> one-thread-per-pixel fallback
 
 
 def _nlm_pair(rng, h, w, scale=0.25):
@@ -101,7 +103,7 @@ def _nlm_pair(rng, h, w, scale=0.25):
     return t, nb
 
 
-@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "rt4", "naive"])
+@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "rt4", "rt2", "rt1", "naive"])
 def test_nlm_accum(ctx, cfg):
     rng = np.random.default_rng(40)
     h, w = 71, 125                                   # > 1 tile in x (58/59 px) and y (64 px), ragged
@@ -142,7 +144,7 @@ def test_nlm_ldr_input(ctx):
     assert rel_err(ctx.nlm_accum(a, b, Z(37, 64), 0.5)[..., :5], ref[..., :5]) < NLM_TOL
 
 
-@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "rt4", "naive"])
+@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "rt4", "rt2", "rt1", "naive"])
 def test_nlm_temporal_fused_equals_dispatch_sequence(ctx, cfg):
     """mid_nlm_temporal(k) == for each neighbour frame: mid_nlm_accum; then mid_normalize -- bit for
     bit -- and both match the oracle; windows clip at the sequence ends (5 frames, k=2)."""
@@ -423,8 +425,8 @@ def test_bilateral_every_radius(ctx, R):
 @pytest.mark.parametrize("search,patch", [((-5, 9), (-3, 4)), ((-12, 13), (-2, 3)), ((0, 1), (-3, 3)), ((-1, 2), (-4, 5)),
                                           ((-16, 17), (-1, 2)), ((-3, 1), (-1, 2)), ((-9, 10), (0, 1)), ((-2, 3), (-5, 6))])
 def test_nlm_unusual_windows(ctx, search, patch):
-    """Asymmetric and degenerate search ranges, every patch size the run-time-range kernel knows and two it does not
-    (1x1 and 11x11 fall to the per-pixel kernel)."""
+    """Asymmetric and degenerate search ranges, patch sizes the run-time-range kernel knows and one it does not
+    (11x11 falls to the per-pixel kernel)."""
     rng = np.random.default_rng(abs(search[0]) * 31 + patch[1])
     t, nb = synth_hdr(rng, 29, 71) * 0.3, synth_hdr(rng, 29, 71) * 0.3
     got = ctx.nlm_accum(t, nb, Z(29, 71), 0.45, search, patch)

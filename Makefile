@@ -3,7 +3,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := image_denoising_filter_amd/csrc
 LIB     := image_denoising_filter_amd/libmi_denoise.so
-SRCS    := $(CSRC)/capi.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/pipeline.cpp $(CSRC)/sharded.cpp \
+SRCS    := $(CSRC)/capi.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/nlm_rt.hip $(CSRC)/nlm_rt4.hip $(CSRC)/pipeline.cpp $(CSRC)/sharded.cpp \
            $(CSRC)/codec/png.cpp $(CSRC)/codec/exr.cpp $(CSRC)/codec/piz.cpp $(CSRC)/codec/image_capi.cpp
 OBJS    := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 HIPFLAGS := -x hip --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Iinclude
@@ -22,13 +22,15 @@ $(LIB): $(OBJS)
 # per-file extras: the NLM kernels gain 2-6 % from LLVM's max-ILP scheduling strategy (A/B on MI355X: 3074 vs 3011
 # Mpixel/s batched, 2882 vs 2710 single frame); the bilateral kernels lose 8 % with it, so it stays off there.
 EXTRA_nlm.hip := -mllvm -amdgpu-sched-strategy=max-ilp
+EXTRA_nlm_rt.hip := $(EXTRA_nlm.hip)
+EXTRA_nlm_rt4.hip := $(EXTRA_nlm.hip)
 # `make TUNING=1` (after `make clean`) also builds the alternative NLM tile shapes that tools/ab_nlm.py selects
 # with MID_NLM_VARIANT; the shipped library has none of them.
 ifdef TUNING
 EXTRA_nlm.hip += -DMID_NLM_TUNING
 endif
 
-build/%.o: $(CSRC)/% $(CSRC)/common.hpp $(CSRC)/codec/image_io.hpp include/mi_denoise.h
+build/%.o: $(CSRC)/% $(CSRC)/common.hpp $(CSRC)/nlm_strip.hpp $(CSRC)/codec/image_io.hpp include/mi_denoise.h
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(HIPFLAGS) $(EXTRA_$(notdir $<)) -c $< -o $@
 

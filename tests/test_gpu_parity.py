@@ -94,7 +94,10 @@ NLM_CFGS = {"ref": dict(search=(-7, 7), patch=(-3, 3)), "bench": dict(search=(-1
             "rt4": dict(search=(-4, 5), patch=(-2, 2)),               # 4x4 patch ([-P,P) at P=2) on the strip kernel
             "rt2": dict(search=(-4, 5), patch=(-1, 1)),               # 2x2 patch ([-P,P) at P=1) on the strip kernel
             "rt1": dict(search=(-6, 7), patch=(0, 1)),                # pixel-wise weights (1x1 patch) on the strip kernel
-            "naive": dict(search=(-2, 3), patch=(-5, 6))}             # 11x11 patch: no strip instantiation -> one-thread-per-pixel fallback
+            "rt10": dict(search=(-3, 4), patch=(-5, 5)), "rt11": dict(search=(-5, 6), patch=(-5, 6)),   # 10x10 .. 13x13 patches:
+            "rt12": dict(search=(-2, 3), patch=(-6, 6)), "rt13": dict(search=(-4, 5), patch=(-6, 7)),   # strips of four rows
+            "rt16": dict(search=(-2, 3), patch=(-8, 8)),              # the largest patch the ABI takes
+            "naive": dict(search=(-2, 3), patch=(-1, 3))}             # lopsided 4x4 patch: no strip instantiation -> one-thread-per-pixel fallback
 
 
 def _nlm_pair(rng, h, w, scale=0.25):
@@ -103,7 +106,7 @@ def _nlm_pair(rng, h, w, scale=0.25):
     return t, nb
 
 
-@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "rt4", "rt2", "rt1", "naive"])
+@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "rt4", "rt2", "rt1", "rt10", "rt11", "rt12", "rt13", "rt16", "naive"])
 def test_nlm_accum(ctx, cfg):
     rng = np.random.default_rng(40)
     h, w = 71, 125                                   # > 1 tile in x (58/59 px) and y (64 px), ragged
@@ -144,7 +147,7 @@ def test_nlm_ldr_input(ctx):
     assert rel_err(ctx.nlm_accum(a, b, Z(37, 64), 0.5)[..., :5], ref[..., :5]) < NLM_TOL
 
 
-@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "rt4", "rt2", "rt1", "naive"])
+@pytest.mark.parametrize("cfg", ["ref", "bench", "generic", "rt7", "rt5", "rt4", "rt2", "rt1", "rt10", "rt11", "rt12", "rt13", "rt16", "naive"])
 def test_nlm_temporal_fused_equals_dispatch_sequence(ctx, cfg):
     """mid_nlm_temporal(k) == for each neighbour frame: mid_nlm_accum; then mid_normalize -- bit for
     bit -- and both match the oracle; windows clip at the sequence ends (5 frames, k=2)."""
@@ -412,6 +415,24 @@ def test_nlm_large_window_eight_wave_workgroups(ctx, search, patch):
         assert np.array_equal(fz[i], ctx.normalize(Wi)), i
 
 
+@pytest.mark.parametrize("patch", [(-5, 5), (-5, 6), (-6, 6), (-6, 7), (-7, 7), (-7, 8), (-8, 8)])
+def test_nlm_large_patches_four_row_strips(ctx, patch):
+    """Patches of 10x10 .. 16x16 run on strips of four rows: the oracle on a frame taller than one 16-row tile and ragged
+    in both directions, fused == accumulate + normalize, and a pixel's bits do not depend on where it sits (shift by 4
+    rows and 3 columns: other wave, other tile, other lane)."""
+    rng = np.random.default_rng(patch[1] - patch[0])
+    search, h, w = (-6, 7), 45, 70
+    t = (synth_hdr(rng, h, w) * 0.25).astype(np.float32)
+    nb = (t * rng.gamma(16.0, 1 / 16.0, (h, w, 1))).astype(np.float32)
+    Wg = ctx.nlm_accum(t, nb, Z(h, w), 0.5, search=search, patch=patch)
+    assert rel_err(Wg[..., :5], oracle.nlm_accum(t, nb, Z(h, w), 0.5, search=search, patch=patch)[..., :5]) < NLM_TOL
+    fused = ctx.nlm_temporal([t], k=0, search=search, patch=patch)[0]
+    assert np.array_equal(fused, ctx.normalize(ctx.nlm_accum(t, t, Z(h, w), 0.5, search=search, patch=patch)))
+    halo = -search[0] + max(-patch[0], patch[1])
+    shifted = ctx.nlm_temporal([np.ascontiguousarray(t[4:, 3:])], k=0, search=search, patch=patch)[0]
+    assert np.array_equal(shifted[halo:-halo, halo:-halo], fused[4 + halo:-halo, 3 + halo:-halo])
+
+
 @pytest.mark.parametrize("R", list(range(1, 25)))
 def test_bilateral_every_radius(ctx, R):
     """radius is a run-time parameter of the ABI (1..24): tuned tiles, the run-time-radius tiled kernel and the
@@ -425,8 +446,7 @@ def test_bilateral_every_radius(ctx, R):
 @pytest.mark.parametrize("search,patch", [((-5, 9), (-3, 4)), ((-12, 13), (-2, 3)), ((0, 1), (-3, 3)), ((-1, 2), (-4, 5)),
                                           ((-16, 17), (-1, 2)), ((-3, 1), (-1, 2)), ((-9, 10), (0, 1)), ((-2, 3), (-5, 6))])
 def test_nlm_unusual_windows(ctx, search, patch):
-    """Asymmetric and degenerate search ranges, patch sizes the run-time-range kernel knows and one it does not
-    (11x11 falls to the per-pixel kernel)."""
+    """Asymmetric and degenerate search ranges, patch sizes the run-time-range kernel knows (11x11: the four-row strips)."""
     rng = np.random.default_rng(abs(search[0]) * 31 + patch[1])
     t, nb = synth_hdr(rng, 29, 71) * 0.3, synth_hdr(rng, 29, 71) * 0.3
     got = ctx.nlm_accum(t, nb, Z(29, 71), 0.45, search, patch)

@@ -12,6 +12,8 @@ def run(n, search, patch):
     tm.tock(0, s); torch.cuda.synchronize(); v = tm.ms()[0] / n / 4; tm.close(); return v
 cases = [((-7, 8), (-2, 3)), ((-5, 6), (-1, 2)), ((-12, 13), (-3, 4)), ((-10, 11), (-2, 3)), ((-4, 5), (-2, 2)), ((-4, 4), (-4, 4)), ((-6, 7), (-4, 5)), ((-7, 8), (-3, 4)), ((-15, 16), (-3, 4)), ((-13, 14), (-2, 3)),
          ((-4, 5), (-1, 1)), ((-4, 5), (0, 1)), ((-7, 7), (-3, 3)), ((-10, 11), (-3, 4)),
-         ((-2, 3), (-5, 6))]   # last: 11x11 patch, no strip instantiation -> nlm_generic_kernel
+         ((-10, 11), (-5, 6)), ((-7, 8), (-6, 7)),
+         ((-5, 6), (-8, 8)),
+         ((-4, 5), (-1, 3))]   # last: lopsided 4x4 patch, no strip instantiation -> nlm_generic_kernel
 run(2, *cases[0])
 print(("k=%d: " % K) + " | ".join("%dx%d/%dx%d %.3f ms" % (sr[1] - sr[0], sr[1] - sr[0], pt[1] - pt[0], pt[1] - pt[0], sorted(run(5, sr, pt) for _ in range(3))[1]) for sr, pt in cases))

@@ -77,7 +77,11 @@ typedef struct mid_bilateral_params {
  * float filteringParameter}, 12 B, pushed at src/main.cpp:865-872 with 0.5f).  The ranges
  * replace `#define WINDOW 7` / `#define PATCH_WINDOW 3` (shaders/nonlocal.comp:5-6) and are
  * HALF-OPEN [lo,hi) like the shader's loops (:36-44): the reference is search [-7,7) patch
- * [-3,3); the 21x21 / 7x7 benchmark configuration is search [-10,11) patch [-3,4). */
+ * [-3,3); the 21x21 / 7x7 benchmark configuration is search [-10,11) patch [-3,4).
+ * Limits: both ranges contain 0, search width <= 64, patch width <= 16.  Every search range and every patch of the forms
+ * [-P,P) and [-P,P] up to 16 wide runs on the LDS-tiled kernel (as long as the tile fits 160 KB: search width <= 51 at a
+ * 7x7 patch); anything else (lopsided patches, wider windows) is computed by a per-pixel kernel -- same results, the
+ * reference's S^2 * P^2 work. */
 typedef struct mid_nlm_params {
     int32_t width;
     int32_t height;

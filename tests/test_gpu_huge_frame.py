@@ -36,21 +36,32 @@ WINDOWS = ((H - SIZE, W - SIZE), (H - SIZE, 0), (8184 - 10, 5000), (16368 - 10, 
 
 
 @pytest.fixture(scope="module")
-def huge():
+def ts():
+    """ONE explicit stream for torch's fills and the library's kernels alike.  (A NULL stream argument means the context's own
+    compute stream, include/mi_denoise.h:15 -- passing torch's default-stream handle, which IS 0, would let a kernel start
+    while the tensor it reads is still being written on torch's stream.)"""
+    return torch.cuda.Stream(device=torch.device("cuda", 0))
+
+
+@pytest.fixture(scope="module")
+def huge(ts):
     assert H * W * 16 > 2 ** 32 and H * W < 2 ** 31
     dev = torch.device("cuda", 0)
-    g = torch.Generator(device=dev).manual_seed(90)
-    img = torch.rand((H, W, 4), device=dev, generator=g, dtype=torch.float32)
-    img[..., :3] *= 0.8
+    with torch.cuda.stream(ts):
+        g = torch.Generator(device=dev).manual_seed(90)
+        img = torch.rand((H, W, 4), device=dev, generator=g, dtype=torch.float32)
+        img[..., :3] *= 0.8
+    ts.synchronize()
     yield img
     del img
     torch.cuda.empty_cache()
 
 
-def test_bilateral_both_addressings_beyond_4_gib(ctx, huge):
+def test_bilateral_both_addressings_beyond_4_gib(ctx, huge, ts):
+    assert ts.cuda_stream != 0
     out = torch.empty_like(huge)
     for layout, orc in ((mid.LAYOUT_TEXTURE, oracle.bilateral_texture), (mid.LAYOUT_LINEAR, oracle.bilateral_linear)):
-        ctx.bilateral_dev(huge.data_ptr(), out.data_ptr(), W, H, 8, 2.0, 0.2, layout, mid.FMT_RGBA32F, torch.cuda.current_stream().cuda_stream)
+        ctx.bilateral_dev(huge.data_ptr(), out.data_ptr(), W, H, 8, 2.0, 0.2, layout, mid.FMT_RGBA32F, ts.cuda_stream)
         torch.cuda.synchronize()
         for y0, x0 in WINDOWS:
             if layout == mid.LAYOUT_LINEAR and (x0 < 8 or x0 + SIZE > W - 8):
@@ -65,13 +76,14 @@ def test_bilateral_both_addressings_beyond_4_gib(ctx, huge):
     del out
 
 
-def test_nlm_fused_and_accumulate_normalize_beyond_4_gib(ctx, huge):
+def test_nlm_fused_and_accumulate_normalize_beyond_4_gib(ctx, huge, ts):
     search, patch, halo = (-10, 11), (-3, 4), 14
-    s = torch.cuda.current_stream().cuda_stream
+    s = ts.cuda_stream
     out = torch.empty_like(huge)
     ctx.nlm_temporal_dev([huge.data_ptr()], [out.data_ptr()], W, H, 0.5, search, patch, 0, 0, 1, mid.FMT_RGBA32F, s)
     # the unfused pair the reference dispatches: nonlocal.comp into the 32-byte-stride weight buffer, then normalize.comp
-    Wb = torch.zeros((H, W, 8), device=huge.device, dtype=torch.float32)
+    with torch.cuda.stream(ts):
+        Wb = torch.zeros((H, W, 8), device=huge.device, dtype=torch.float32)      # (the fill is ordered before the accumulate: same stream)
     assert Wb.numel() * 4 > 2 ** 33
     out2 = torch.empty_like(huge)
     p = mid.NlmParams(W, H, 0.5, search[0], search[1], patch[0], patch[1], mid.FMT_RGBA32F)
@@ -94,8 +106,8 @@ def test_nlm_fused_and_accumulate_normalize_beyond_4_gib(ctx, huge):
     del Wb, out, out2
 
 
-def test_pack_unpack_beyond_4_gib(ctx, huge):
-    s = torch.cuda.current_stream().cuda_stream
+def test_pack_unpack_beyond_4_gib(ctx, huge, ts):
+    s = ts.cuda_stream
     n = H * W * 4
     u8 = torch.empty((H, W, 4), device=huge.device, dtype=torch.uint8)
     assert mid.lib.mid_pack_u8(ctx.handle, huge.data_ptr(), n, u8.data_ptr(), s) == 0

@@ -13,7 +13,9 @@
  *   - all image pointers are DEVICE pointers unless a name says host; the caller owns every
  *     buffer (reference: the application owns every VkBuffer/VkImage, src/main.cpp:1398-1437).
  *   - `stream` is a hipStream_t passed as void*; NULL = the context's own compute stream.
- *     Calls are asynchronous on that stream.
+ *     Calls are asynchronous on that stream.  (The legacy default stream's handle is 0 too, so it cannot be named here:
+ *     a caller whose buffers are produced on the default stream -- e.g. torch.cuda.current_stream().cuda_stream == 0 --
+ *     passes a created stream that it orders after that work, or synchronises first.)
  *   - images are row-major, pixel index = width*y + x (shaders/bialteral.comp:81).
  *   - there is NO CPU fallback: without a usable HIP device mid_ctx_create fails.
  */

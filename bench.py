@@ -374,7 +374,10 @@ def main():
     # the process group is gloo (RCCL refuses two ranks on one device), halo frames are staged through host memory.  Real
     # kernels, real control flow, no xGMI: the JSON line says so ("rehearsal": true) and is never a scaling measurement.
     rehearse = os.environ.get("MID_BENCH_REHEARSE") == "1"
-    dev_index = local_rank % torch.cuda.device_count() if rehearse else local_rank
+    n_visible = max(torch.cuda.device_count(), 1)
+    # (a launcher that narrows each rank's visibility to its own GPU -- ROCR/HIP_VISIBLE_DEVICES per rank -- leaves one visible
+    # device, index 0, in every process: LOCAL_RANK is then not a device index)
+    dev_index = local_rank % n_visible if (rehearse or local_rank >= n_visible) else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     coll_device = torch.device("cpu") if rehearse else device        # where the small tensors of the collectives live

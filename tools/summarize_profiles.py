@@ -57,13 +57,16 @@ if main:   # bench.py --no-extras: only the timed loop's launches, so Calls/Aver
         for r in [r for r in rows if "mid::" in r["Name"]] + [r for r in rows if "mid::" not in r["Name"]][:5]:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                         r["MinNs"], r["MaxNs"], r["StdDev"]])
-        # the TIMED launches only: the run is `--steps 5 --warmup 2`, so the first 2 launches of the dominant kernel (in
-        # start order) are warm-ups; the row below averages the other 5 and is the one to hold against
-        # roofline.avg_launch_ms of a bench.py run
+        # the TIMED launches only: the first `warmup` launches of the dominant kernel (in start order) are warm-ups; the row
+        # below averages the others and is the one to hold against roofline.avg_launch_ms of a bench.py run
         tr = sorted(glob.glob(os.path.join(src, "trace_main", "*", "*_kernel_trace.csv")), key=os.path.getmtime, reverse=True)
         if tr:
             d = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), short(r["Kernel_Name"]))
                         for r in csv.DictReader(open(tr[0])) if "nlm_strip_kernel" in r["Kernel_Name"]))
+            # (tools/run_profiles.sh records the pass's warm-up count: since round 3 the trace_main pass is the DEFAULT command,
+            # --steps 20 --warmup 3, the one the driver times; older collections used --steps 5 --warmup 2)
+            wfile = os.path.join(src, "trace_main.warmup")
+            WARMUP = int(open(wfile).read().strip()) if os.path.exists(wfile) else 2
             timed = [x[1] for x in d[WARMUP:]]
             if timed:
                 mean = sum(timed) / len(timed)

@@ -433,6 +433,35 @@ def test_nlm_large_patches_four_row_strips(ctx, patch):
     assert np.array_equal(shifted[halo:-halo, halo:-halo], fused[4 + halo:-halo, 3 + halo:-halo])
 
 
+def test_impulse_response_against_the_float64_restatement(ctx):
+    """One bright texel off-centre in a flat frame (and an impulse in the neighbour frame only, for NLM): the response is
+    the filter's kernel, so a transposed offset, a mirrored window or a wrong window edge shows as a displaced or
+    truncated footprint.  Compared with the float64 NumPy restatement (tests/np_reference.py), which shares no code with
+    the oracle or the kernels; lopsided ranges on purpose."""
+    import np_reference as npr
+    h, w = 41, 53
+    img = np.full((h, w, 4), 0.25, np.float32)
+    img[..., 3] = 1.0
+    img[17, 31, :3] = (0.9, 0.35, 0.6)                       # (y, x) = (17, 31): not on a diagonal of the frame
+    for R, ss, sc in ((4, 2.0, 0.6), (8, 3.0, 0.8), (7, 2.5, 0.7)):
+        num, den = npr.bilateral_texture(img, R, ss, sc)
+        ref = num / den[..., None]
+        got = ctx.bilateral(img, R, ss, sc, "texture")
+        assert rel_err(got, ref) < 1e-5, R
+        # the footprint itself: in the interior the impulse is felt exactly inside its (2R+1)^2 window
+        flat = got[R + 2, R + 2, 0]
+        felt = np.abs(got[2 * R:h - 2 * R, 2 * R:w - 2 * R, 0] - flat) > 1e-6
+        ys, xs = np.nonzero(felt)
+        assert ys.min() + 2 * R >= 17 - R and ys.max() + 2 * R <= 17 + R and xs.min() + 2 * R >= 31 - R and xs.max() + 2 * R <= 31 + R
+        assert rel_err(ctx.bilateral(img, R, ss, sc, "linear"), npr.bilateral_linear(img, R, ss, sc)) < 1e-5, R
+    t = np.full((h, w, 4), 0.25, np.float32); t[..., 3] = 1.0
+    nb = t.copy(); nb[17, 31, :3] = (0.5, 0.3, 0.4)
+    for search, patch in (((-3, 6), (-2, 3)), ((-7, 7), (-3, 3)), ((-5, 2), (-1, 2)), ((-4, 5), (-5, 6))):
+        num, den = npr.nlm_sums(t, nb, 0.5, search, patch)
+        W = ctx.nlm_accum(t, nb, Z(h, w), 0.5, search=search, patch=patch)
+        assert rel_err(W[..., :4], num) < NLM_TOL and rel_err(W[..., 4], den) < NLM_TOL, (search, patch)
+
+
 @pytest.mark.parametrize("R", list(range(1, 25)))
 def test_bilateral_every_radius(ctx, R):
     """radius is a run-time parameter of the ABI (1..24): tuned tiles, the run-time-radius tiled kernel and the

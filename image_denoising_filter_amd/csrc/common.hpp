@@ -51,8 +51,10 @@ inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 // mid_nlm_temporal with the output format as an argument: out_u8 != 0 writes RGBA8 frames (pack_rgba8 of the
 // normalized pixel) instead of float4 ones -- used by the frame pipeline's u8 variant, not exported.
+// `corunning` != 0: the caller keeps launches on two streams in flight (the frame pipeline), so the last round of one launch
+// overlaps the first of the next -- the HALF launch shape for a small launch's last round (nlm.hip, tail_split) is not used.
 int nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *const *frames, int n_frames, int k,
-                     int first, int count, void *const *out, int out_u8, void *stream);
+                     int first, int count, void *const *out, int out_u8, void *stream, int corunning = 0);
 
 // Raise the dynamic-LDS limit of `kern` once per context (kernels here use up to 160 KB).
 inline int ensure_lds(mid_ctx *ctx, const void *kern, size_t bytes)

@@ -25,6 +25,10 @@
 // Out-of-image texels are vec4(0) for both images (LDS halo zero-filled).
 #include "nlm_strip.hpp"
 
+#ifndef MID_NLM_TAIL_SPLIT
+#define MID_NLM_TAIL_SPLIT 1     /* 0: A/B builds without the HALF launch shape for the last round of small launches */
+#endif
+
 namespace mid {
 
 // Any other search/patch ranges: one thread per pixel, straight from the shader text
@@ -86,6 +90,26 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
     }
 }
 
+// The last round of a SMALL launch.  A tuned launch is tiles x frames workgroups of 4 waves, two per CU (76 KB tiles): `slots` at a
+// time.  When the last round fills at most half of the CUs' slots -- one workgroup per CU or fewer -- every wave of it sits alone
+// on its SIMD and issues at half rate, so the round takes as long as a full one: one 1080p frame is 1156 workgroups = 2.26 rounds and
+// pays for 3.  Those workgroups are launched in the HALF shape instead (eight waves on the same tile, half a strip each, same bits:
+// nlm_strip.hpp), which brings two waves per SIMD back and ends the round in 0.6 of the time.  Only for launches of a few rounds:
+// in a long launch the last round is noise, and the headline launch stays ONE kernel.  false = launch everything the usual way.
+static bool tail_split(const mid_ctx *ctx, const NlmArgs &a, int patch_w, bool fused, unsigned &full, unsigned &rem)
+{
+#if MID_NLM_TAIL_SPLIT
+    const unsigned slots = 2u * (unsigned)ctx->cu_count;
+    const unsigned nwg = nlm_tile_workgroups(a.w, a.h, patch_w, fused ? a.count : 1);
+    rem = nwg % slots;
+    full = nwg - rem;
+    return !a.corunning && rem > 0 && rem <= (unsigned)ctx->cu_count && full / slots <= 8;
+#else
+    (void)ctx; (void)a; (void)patch_w; (void)fused; full = rem = 0;
+    return false;
+#endif
+}
+
 template <int FMT, bool FUSED>
 static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s)
 {
@@ -137,6 +161,10 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
         // faster, so the choice goes by launch size.
         if (a.count == 1) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3, false, MID_NLM_SINGLE_SYP>(ctx, a, s);
 #endif
+        if (unsigned full, rem; tail_split(ctx, a, 7, FUSED, full, rem)) {
+            if (int rc = launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s, 0, full)) return rc;
+            return launch_strip<-10, 11, -3, 4, 4, 8, FMT, FUSED, false, 3, false, 0, 0, true>(ctx, a, s, full, rem);
+        }
         return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s);
     }
     if (p->search_lo == -7 && p->search_hi == 7 && p->patch_lo == -3 && p->patch_hi == 3) {     // nonlocal.comp:5-6 as shipped
@@ -144,6 +172,10 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
 #if MID_NLM_SINGLE_SYP_REF > 0
         if (a.count == 1) return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2, false, MID_NLM_SINGLE_SYP_REF>(ctx, a, s);   // 77 x 43 texels = 51.7 KB: three workgroups per CU
 #endif
+        if (unsigned full, rem; tail_split(ctx, a, 6, FUSED, full, rem)) {
+            if (int rc = launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2>(ctx, a, s, 0, full)) return rc;
+            return launch_strip<-7, 7, -3, 3, 4, 8, FMT, FUSED, false, 2, false, 0, 0, true>(ctx, a, s, full, rem);
+        }
         return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2>(ctx, a, s);
     }
     // Any other search window: the same strip kernel with the search range as a run-time argument (LDS pitch no longer a folded
@@ -214,7 +246,7 @@ extern "C" int mid_nlm_temporal(mid_ctx *ctx, const mid_nlm_params *p, const voi
 }
 
 int mid::nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *const *frames, int n_frames, int k,
-                          int first, int count, void *const *out, int out_u8, void *stream)
+                          int first, int count, void *const *out, int out_u8, void *stream, int corunning)
 {
     Bind b(ctx, stream);
     if (b.rc) return b.rc;
@@ -231,7 +263,7 @@ int mid::nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *con
         const int hi = c0 + cn - 1 + k > n_frames - 1 ? n_frames - 1 : c0 + cn - 1 + k;
         NlmArgs a{};
         a.w = p->width; a.h = p->height; set_scales(a, p->filteringParameter);
-        a.n_frames = hi - lo + 1; a.k = k; a.first = c0 - lo; a.count = cn; a.out_u8 = out_u8;
+        a.n_frames = hi - lo + 1; a.k = k; a.first = c0 - lo; a.count = cn; a.out_u8 = out_u8; a.corunning = corunning;
         for (int f = lo; f <= hi; ++f) {
             MID_REQUIRE(frames[f] != nullptr, "nlm_temporal: frame %d is NULL", f);
             a.frames.p[f - lo] = frames[f];

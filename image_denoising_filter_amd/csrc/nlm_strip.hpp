@@ -36,6 +36,7 @@ struct NlmArgs {
     float kexp;            // -log2(e) / h^2 (per-pixel fallback kernel)
     float sk, inv_sk;      // sqrt(log2(e))/h and its reciprocal: the strip kernels carry the exponent scale in the colours
     int tiles_x, tiles_y;
+    unsigned wg_first;     // this launch covers the workgroups [wg_first, wg_first + gridDim.x) of the tiles x frames grid (0: all of it)
     // accumulate mode (one dispatch of nonlocal.comp)
     const void *target;
     const void *neighbour;
@@ -44,6 +45,7 @@ struct NlmArgs {
     // fused temporal mode
     int n_frames, k, first, count;
     int out_u8;            // fused mode: outputs are RGBA8 frames (pack_rgba8) instead of float4
+    int corunning;         // host side only: launches of the frame pipeline overlap each other (no HALF tail, nlm.hip)
     FrameTable frames;
     OutTable outs;
 };
@@ -73,6 +75,30 @@ __device__ __forceinline__ void vertical_box(const float (&D)[R + PW - 1], float
     for (int k = 0; k < R; ++k) {
         if (k % PW == 0) V[k] = (k == 0) ? S[0] : Pf[k + PW - 1];
         else V[k] = S[k] + Pf[k + PW - 1];
+    }
+}
+
+// The vertical sums of HALF an 8-row strip -- output rows 0..3 (lower == false) or 4..7 (lower == true) from the 4 + PW - 1 rows they
+// need -- with the additions of vertical_box<PW, 8> for those rows, in its order: the block decomposition is evaluated in the 8-row
+// strip's frame with the rows outside this half left out (none of them feeds the half's outputs; they fold away).  Two waves that take
+// one half each therefore produce the bits one wave produces for the whole strip.
+template <int PW, bool LOWER>
+__device__ __forceinline__ void vertical_box_half(const float (&D)[4 + PW - 1], float (&V)[4])
+{
+    constexpr int N8 = 8 + PW - 1;
+    float D8[N8], V8[8];
+    if constexpr (LOWER) {
+#pragma unroll
+        for (int m = 0; m < N8; ++m) D8[m] = (m >= 4) ? D[m - 4] : 0.f;
+        vertical_box<PW, 8>(D8, V8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) V[k] = V8[k + 4];
+    } else {
+#pragma unroll
+        for (int m = 0; m < N8; ++m) D8[m] = (m < 4 + PW - 1) ? D[m] : 0.f;
+        vertical_box<PW, 8>(D8, V8);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) V[k] = V8[k];
     }
 }
 
@@ -115,7 +141,7 @@ constexpr int nlm_min_waves(bool rts, bool multi, int pw)
     return MID_NLM_MIN_WAVES > 0 ? MID_NLM_MIN_WAVES : (rts && multi && (pw == 4 || pw >= 7)) ? 2 : 1;
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0, int PF = 0>
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0, int PF = 0, bool HALF = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SYP > 0 ? 3 : nlm_min_waves(SLO == 0 && SHI == 0, MULTI, PHI - PLO), SYP > 0 ? 3 : 2)))
 void nlm_strip_kernel(const NlmArgs a)
 {
@@ -135,13 +161,19 @@ void nlm_strip_kernel(const NlmArgs a)
     static_assert(PLO <= 0 && PHI >= 1 && (RTS || SHI - SLO >= 1), "ranges must contain 0");
     static_assert(!(SYP > 0 && SYM), "the symmetry ablation is single-pass");
     static_assert(PF == 0 || (!SYM && SYP == 0), "the prefetching loop exists for the plain single-pass kernel");
+    // HALF: the launch shape for the last, partly filled round of a small launch.  Eight waves per workgroup on the SAME 32-row
+    // tile, each taking half of an 8-row strip (R = 4; even waves the upper, odd waves the lower four rows) with the strip's own
+    // vertical sums (vertical_box_half): identical output bits, 0.6 of a strip's instructions per wave, and two waves per SIMD on
+    // a CU that holds this workgroup alone -- where a 4-wave workgroup alone leaves every wave a SIMD to itself at half issue rate.
+    static_assert(!HALF || (R == 4 && NW == 8 && !SYM && SYP == 0 && PF == 0 && MID_NLM_WALK > 0), "HALF: eight waves of four rows on the walk loop");
 
     extern __shared__ float4 lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const unsigned tiles = (unsigned)(a.tiles_x * a.tiles_y);
-    const int fz = (int)(blockIdx.x / tiles);
-    const unsigned trem = xcd_remap_in_frame(blockIdx.x - (unsigned)fz * tiles, tiles, (unsigned)fz);
+    const unsigned bid = blockIdx.x + a.wg_first;
+    const int fz = (int)(bid / tiles);
+    const unsigned trem = xcd_remap_in_frame(bid - (unsigned)fz * tiles, tiles, (unsigned)fz);
     const int ty = (int)(trem / (unsigned)a.tiles_x), tx = (int)(trem - (unsigned)ty * a.tiles_x);
 
     const int w = a.w, h = a.h;
@@ -426,9 +458,12 @@ void nlm_strip_kernel(const NlmArgs a)
             // shader's y-outer loop, nonlocal.comp:36-38) in the order the 441 non-negative terms are added.
             constexpr int WALK = (!RTS && SHI - SLO < MID_NLM_WALK) ? SHI - SLO : MID_NLM_WALK;   // (a tuned window narrower than the run: one run per search column)
             static_assert(SYP == 0 || SYP == WALK, "the multi-pass tile's passes are the runs of the walk");
-            constexpr bool EARLY = NL >= 1;     // the row that leaves the window is no centre row: its slot can be refilled right after the distance phase
+            constexpr bool EARLY = NL >= 1;
+            const bool lower_half = HALF && (__builtin_amdgcn_readfirstlane(wv) & 1) != 0;      // (scalar: a real branch, not both sides under masks)     // the row that leaves the window is no centre row: its slot can be refilled right after the distance phase
             // one offset of a run: window row r lives in register slot (j + r) % DR
-            auto step = [&](int j, float4 (&n)[DR], const float4 *nextp, bool more) {
+            // (LT: std::bool_constant -- the lower half of a strip in the HALF shape; the two halves are two copies of the loop, chosen
+            // per wave by a scalar branch around a whole run, so that each copy is straight-line code)
+            auto step = [&](auto LT, int j, float4 (&n)[DR], const float4 *nextp, bool more) {
                 phase(PL{}, P0{});
                 float D[DR];
 #pragma unroll
@@ -445,7 +480,8 @@ void nlm_strip_kernel(const NlmArgs a)
                 }
                 phase(P0{}, P1{});
                 float V[R];
-                vertical_box<PW, R>(D, V);
+                if constexpr (HALF) vertical_box_half<PW, decltype(LT)::value>(D, V);
+                else vertical_box<PW, R>(D, V);
                 phase(P1{}, P2{});
                 float dd[R], ww[R];
 #pragma unroll
@@ -466,17 +502,18 @@ void nlm_strip_kernel(const NlmArgs a)
                 phase(P4{}, PL{});
             };
             // `steps` <= WALK consecutive search rows at one search column; FULL: steps == WALK is known at compile time
-            auto run = [&](const bool FULL, const float4 *colp, int steps) __attribute__((always_inline)) {
+            auto run = [&](auto LT, const bool FULL, const float4 *colp, int steps) __attribute__((always_inline)) {
                 float4 n[DR];
 #pragma unroll
                 for (int m = 0; m < DR; ++m) n[m] = colp[m * LW];
 #pragma unroll
                 for (int j = 0; j < WALK; ++j) {
-                    if (FULL || j < steps) step(j, n, colp + (DR + j) * LW, FULL ? j + 1 < WALK : j + 1 < steps);
+                    if (FULL || j < steps) step(LT, j, n, colp + (DR + j) * LW, FULL ? j + 1 < WALK : j + 1 < steps);
                 }
                 // rows still in the window that never were centre rows: keep their alpha formally live (see above)
+                const float last_w = accw[R - 1];
 #pragma unroll
-                for (int m = 0; m < DR; ++m) asm volatile("" ::"v"(n[m].w), "v"(accw[R - 1]));
+                for (int m = 0; m < DR; ++m) asm volatile("" ::"v"(n[m].w), "v"(last_w));
             };
             for (int sy0 = 0; sy0 < SW; sy0 += WALK) {
                 if constexpr (SYP > 0) {
@@ -489,8 +526,13 @@ void nlm_strip_kernel(const NlmArgs a)
                 if (wave_active) {
                     const int steps = sy0 + WALK < SW ? WALK : SW - sy0;
                     const float4 *rowp = lds + (wv * R + (SYP > 0 ? 0 : sy0)) * LW + lane;
-                    if (steps == WALK) { for (int sx = 0; sx < SW; ++sx) run(true, rowp + sx, steps); }
-                    else { for (int sx = 0; sx < SW; ++sx) run(false, rowp + sx, steps); }
+                    if (HALF && lower_half) {
+                        if (steps == WALK) { for (int sx = 0; sx < SW; ++sx) run(std::bool_constant<HALF>{}, true, rowp + sx, steps); }
+                        else { for (int sx = 0; sx < SW; ++sx) run(std::bool_constant<HALF>{}, false, rowp + sx, steps); }
+                    } else {
+                        if (steps == WALK) { for (int sx = 0; sx < SW; ++sx) run(std::false_type{}, true, rowp + sx, steps); }
+                        else { for (int sx = 0; sx < SW; ++sx) run(std::false_type{}, false, rowp + sx, steps); }
+                    }
                 }
             }
         } else if constexpr (SYP > 0) {
@@ -561,8 +603,8 @@ void nlm_strip_kernel(const NlmArgs a)
     }
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0, int PF = 0>
-static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, int U = 1, bool SYM = false, int SYP = 0, int PF = 0, bool HALF = false>
+static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s, unsigned wg_first = 0, unsigned wg_count = ~0u)
 {
     constexpr bool RTS = (SLO == 0 && SHI == 0);
     constexpr int PW = PHI - PLO;
@@ -570,7 +612,7 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
     const int SW = RTS ? a.shi - a.slo : SHI - SLO;
     const int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + (SYP > 0 ? SYP : SW) - 1;
     const size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
-    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, SYM, SYP, PF>;
+    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, U, SYM, SYP, PF, HALF>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     // run-time-range instantiations are launched with different tile sizes: raise their limit to the device maximum once
@@ -578,9 +620,21 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s)
     a.tiles_x = (int)cdiv(a.w, VW);
     a.tiles_y = (int)cdiv(a.h, TILE_H);
     const unsigned nwg = (unsigned)a.tiles_x * a.tiles_y * (FUSED ? a.count : 1);
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(NW * 64), lds_bytes, s, a);
+    // (a launch may cover a sub-range of the tiles x frames grid: the tail of a small launch goes to the HALF shape)
+    if (wg_first >= nwg) return MID_OK;
+    const unsigned n = wg_count < nwg - wg_first ? wg_count : nwg - wg_first;
+    if (n == 0) return MID_OK;
+    a.wg_first = wg_first;
+    hipLaunchKernelGGL(kern, dim3(n), dim3(NW * 64), lds_bytes, s, a);
+    a.wg_first = 0;
     MID_HIP(hipGetLastError());
     return MID_OK;
+}
+
+// Workgroups of a tuned launch (4 waves x 8 rows per tile): what the tail rule of dispatch_ranges needs before launching.
+inline unsigned nlm_tile_workgroups(int w, int h, int patch_w, int frames)
+{
+    return cdiv((unsigned)w, (unsigned)(64 - (patch_w - 1))) * cdiv((unsigned)h, 32u) * (unsigned)frames;
 }
 
 // Run-time search windows: defined in nlm_rt.hip / nlm_rt4.hip.  *handled = false: no strip instantiation for this patch (or the tile

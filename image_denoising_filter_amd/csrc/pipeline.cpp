@@ -147,7 +147,7 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
         MID_HIP(hipEventRecord(c0.ev[bi], cs));
         // out_u8: GetImageFromGPU's u8 conversion (src/main.cpp:97-103) in the kernel's epilogue -- a quarter of the
         // bytes to write and to download
-        if (int rc = nlm_temporal_out(ctx, p, tbl, need - lo + 1, k, b0 - lo, bn, (void *const *)o, out_u8 ? 1 : 0, cs)) return rc;
+        if (int rc = nlm_temporal_out(ctx, p, tbl, need - lo + 1, k, b0 - lo, bn, (void *const *)o, out_u8 ? 1 : 0, cs, 1)) return rc;
         MID_HIP(hipEventRecord(c1.ev[bi], cs));
 
         while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }

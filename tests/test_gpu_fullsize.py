@@ -85,6 +85,35 @@ def test_nlm_batch_equals_single_launches_and_is_deterministic(ctx, frame):
         assert np.array_equal(batch[i], single) and np.array_equal(batch[i], again[i])
 
 
+@pytest.mark.parametrize("cfg", [dict(search=(-10, 11), patch=(-3, 4)), dict(search=(-7, 7), patch=(-3, 3))])
+@pytest.mark.parametrize("ldr", [False, True])
+def test_half_shape_of_a_small_launchs_last_round_is_bit_identical(ctx, frame, cfg, ldr):
+    """One 1080p frame is 1156 workgroups = 2 full rounds + 132: the 132 run in the HALF shape (eight waves per tile, half a
+    strip each, csrc/nlm_strip.hpp), fused and unfused alike; a 3-frame launch (6 rounds + 396) runs entirely in the standard
+    shape.  Same bits, for both tuned windows and both texel formats -- and the tail covers the bottom-right tiles, so
+    the ragged last tile row (1080 = 33 x 32 + 24) and column are in it."""
+    rng = np.random.default_rng(21)
+    if ldr:
+        fr = [np.clip(frame[..., :4] * 0.12 * rng.gamma(16.0, 1 / 16.0, (H, W, 1)), 0, 1) for _ in range(3)]
+        fr = [(f * 255).astype(np.uint8) for f in fr]
+        for f in fr:
+            f[..., 3] = 255
+    else:
+        fr = [(frame * 0.25 * rng.gamma(16.0, 1 / 16.0, (H, W, 1))).astype(np.float32) for _ in range(3)]
+    batch = ctx.nlm_temporal(fr, k=0, **cfg)
+    for i in (0, 2):
+        single = ctx.nlm_temporal([fr[i]], k=0, **cfg)[0]
+        assert np.array_equal(batch[i], single), i
+    unfused = ctx.normalize(ctx.nlm_accum(fr[1], fr[1], np.zeros((H, W, 8), np.float32), 0.5, **cfg))
+    assert np.array_equal(batch[1], unfused)
+    # temporal launches never use the shape; a one-output temporal launch over the same frames still agrees with the sequence
+    t1 = ctx.nlm_temporal(fr, k=1, first=1, count=1, **cfg)[0]
+    Wt = np.zeros((H, W, 8), np.float32)
+    for f in fr:
+        Wt = ctx.nlm_accum(fr[1], f, Wt, 0.5, **cfg)
+    assert np.array_equal(t1, ctx.normalize(Wt))
+
+
 def test_constant_frame_properties(ctx):
     img = np.tile(np.float32([0.25, 0.5, 2.0, 1.0]), (H, W, 1))
     out = ctx.bilateral(img, 8, 2.0, 0.2)

@@ -120,8 +120,9 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
     // The tile shape is the same for every launch size on purpose: the block-sum decomposition of
     // vertical_box makes the rounding of a pixel depend on its row within the strip, so a fixed R keeps
     // the output bits independent of batch size, sharding and fused-vs-dispatch-sequence (tested).  (A
-    // shorter strip, R=6, filled the CUs better for ONE 1080p frame -- 0.69 vs 0.74 ms -- but would have
-    // made single-frame and batched results differ in the last bit.)
+    // shorter strip, R=6, filled the CUs better for ONE 1080p frame but would have made single-frame and
+    // batched results differ in the last bit; the HALF shape of tail_split above splits strips into rows
+    // 0-3 / 4-7 with the 8-row strip's own additions instead, so it may be used wherever it is faster.)
     const bool multi = FUSED && a.k > 0;
 #ifdef MID_NLM_TUNING   // `make TUNING=1`: extra tile shapes selectable per process for tools/ab_nlm.py; not in the shipped library
     static const int variant = getenv("MID_NLM_VARIANT") ? atoi(getenv("MID_NLM_VARIANT")) : 0;
@@ -153,14 +154,6 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
         }
 #endif
         if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3>(ctx, a, s);
-#if MID_NLM_SINGLE_SYP > 0
-        // A launch over ONE frame (the frame pipeline's launches, mid_nlm_accum, latency-bound callers) is 1156 workgroups: on
-        // the 512 slots of the 76 KB single-pass tile that is 2.26 rounds, the last one a quarter full.  The multi-pass tile
-        // (52.5 KB, three workgroups per CU, 768 slots: 1.5 rounds) walks the same offsets in the same order -- identical
-        // output bits (tested) -- and finishes a lone frame 10 % sooner; over many frames the single-pass tile is as fast or
-        // faster, so the choice goes by launch size.
-        if (a.count == 1) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3, false, MID_NLM_SINGLE_SYP>(ctx, a, s);
-#endif
         if (unsigned full, rem; tail_split(ctx, a, 7, FUSED, full, rem)) {
             if (int rc = launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s, 0, full)) return rc;
             return launch_strip<-10, 11, -3, 4, 4, 8, FMT, FUSED, false, 3, false, 0, 0, true>(ctx, a, s, full, rem);
@@ -169,9 +162,6 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
     }
     if (p->search_lo == -7 && p->search_hi == 7 && p->patch_lo == -3 && p->patch_hi == 3) {     // nonlocal.comp:5-6 as shipped
         if (multi) return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, FUSED, 2>(ctx, a, s);
-#if MID_NLM_SINGLE_SYP_REF > 0
-        if (a.count == 1) return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2, false, MID_NLM_SINGLE_SYP_REF>(ctx, a, s);   // 77 x 43 texels = 51.7 KB: three workgroups per CU
-#endif
         if (unsigned full, rem; tail_split(ctx, a, 6, FUSED, full, rem)) {
             if (int rc = launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2>(ctx, a, s, 0, full)) return rc;
             return launch_strip<-7, 7, -3, 3, 4, 8, FMT, FUSED, false, 2, false, 0, 0, true>(ctx, a, s, full, rem);

@@ -15,12 +15,6 @@
 #ifndef MID_NLM_WALK
 #define MID_NLM_WALK 21          /* search rows walked innermost in runs of this many (0 = search column innermost, the round-1/2 order) */
 #endif
-#ifndef MID_NLM_SINGLE_SYP
-#define MID_NLM_SINGLE_SYP 0     /* search rows per tile fill of the single-frame launches (0 = the single-pass tile for every launch size); must equal MID_NLM_WALK when both are set */
-#endif
-#ifndef MID_NLM_SINGLE_SYP_REF
-#define MID_NLM_SINGLE_SYP_REF 0 /* the same for the reference's shipped windows */
-#endif
 #ifndef MID_NLM_DIST_SPLIT
 #define MID_NLM_DIST_SPLIT 0
 #endif

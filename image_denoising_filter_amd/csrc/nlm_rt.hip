@@ -1,4 +1,5 @@
-// nlm_rt.hip -- NLM strip kernel, search window as a run-time argument, patches 1x1 .. 9x9 (strips of eight rows).
+// nlm_rt.hip -- the NLM strip kernel with the search window as a run-time argument, patches 1x1 .. 9x9 (strips of eight rows): shaders/nonlocal.comp:28-72 at other
+// WINDOW / PATCH_WINDOW values than the shipped ones (:5-6), which nlm.hip's tuned instantiations serve.  Kernel and algorithm: nlm_strip.hpp, nlm.hip.
 #include "nlm_strip.hpp"
 
 namespace mid {

@@ -1,4 +1,5 @@
-// nlm_rt4.hip -- NLM strip kernel, search window as a run-time argument, patches 10x10 .. 16x16 (strips of four rows).
+// nlm_rt4.hip -- the NLM strip kernel with the search window as a run-time argument, patches 10x10 .. 16x16 (strips of four rows): shaders/nonlocal.comp:28-72 at other
+// WINDOW / PATCH_WINDOW values than the shipped ones (:5-6), which nlm.hip's tuned instantiations serve.  Kernel and algorithm: nlm_strip.hpp, nlm.hip.
 #include "nlm_strip.hpp"
 
 namespace mid {

@@ -3,7 +3,8 @@
 
 Metric (BASELINE.json): Mpixel/s of non-local means, 21x21 search / 7x7 patch, on 1920x1080
 RGBA32F frames resident in HBM.  A "step" is one pass of the hot path over one batch of
-`--frames` synthetic frames per GPU (one fused launch: accumulate + normalize per frame).
+`--frames` synthetic frames per GPU (one fused launch: accumulate + normalize per frame;
+default 31 = a whole number of rounds of workgroups on the chip, see --frames below).
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); single-frame NLM shards by
 frame with no data-path collective, so every rank filters its own batch ("weak" scaling) and
 value = all ranks' pixels / max-over-ranks time.  After the timed region (outside it) the run
@@ -344,7 +345,10 @@ def main():
                          "bench.py spawns the N ranks itself")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=16, help="frames per GPU per step")
+    # 31: a 1080p frame is 1156 workgroups and an MI355X holds 512 at a time (two 76 KB tiles on each of 256 CUs), so a launch over
+    # 31 frames is 69.99 rounds of workgroups -- no last, mostly empty round (16 frames: 36.1 rounds, 1.7 % slower per frame;
+    # profiles/r03_frames_per_launch_sweep.txt).  The side measurements below keep their 16-frame shapes.
+    ap.add_argument("--frames", type=int, default=31, help="frames per GPU per step (one fused launch)")
     ap.add_argument("--workload", choices=["nlm", "bilateral"], default="nlm",
                     help="what the timed region measures: nlm = BASELINE configs[2] (the north_star target, default); "
                          "bilateral = configs[1], r=8, linear-buffer layout, one launch per frame")
@@ -519,6 +523,7 @@ def main():
         except Exception as e:          # an extra must never take the measurement down with it
             also[name + "_error"] = f"{type(e).__name__}: {e}"
 
+    XF = 16                             # frames of the 16-frame side measurements (bilateral batch, short pipelines), whatever --frames is
     if not args.no_extras:
         def time_gpu(fn, n=10):
             fn()
@@ -561,8 +566,9 @@ def main():
 
         def extra_bilateral_batch():
             # all F resident frames in ONE launch (mid_bilateral_batch): every round of workgroups is full
-            s = time_gpu(lambda: ctx.bilateral_batch_dev(fptr, optr, W, H, 8, 2.0, 0.2, mid.LAYOUT_LINEAR, mid.FMT_RGBA32F, stream), 5)
-            also["bilateral_r8_linear_batch"] = {"Mpixel/s": round(F * NPIX / 1e6 / s, 1), "ms_per_frame": round(s * 1e3 / F, 4), "frames": F,
+            nb = min(F, XF)
+            s = time_gpu(lambda: ctx.bilateral_batch_dev(fptr[:nb], optr[:nb], W, H, 8, 2.0, 0.2, mid.LAYOUT_LINEAR, mid.FMT_RGBA32F, stream), 5)
+            also["bilateral_r8_linear_batch"] = {"Mpixel/s": round(nb * NPIX / 1e6 / s, 1), "ms_per_frame": round(s * 1e3 / nb, 4), "frames": nb,
                                                  "valu_frac": round(BIL_FLOP_PER_PX * F * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
                                                  "hbm_GBs": round(BIL_BYTES_PER_PX * F * NPIX / s / 1e9, 1)}
 
@@ -727,7 +733,7 @@ def main():
         def extra_pipeline():
             if rank == 0 and world == 1:
                 # PCIe-inclusive: pinned host frames in, host frames out, overlapped streams (never `value`)
-                hf = [f.cpu().numpy() for f in frames]
+                hf = [f.cpu().numpy() for f in frames[:XF]]
                 ctx.sequence_nlm(hf[:2], k=0, overlap=True, search=SEARCH, patch=PATCH)      # first-touch of pinned memory
                 _, (wall, kern, copy) = ctx.sequence_nlm(hf, k=0, overlap=True, search=SEARCH, patch=PATCH)
                 _, (wall0, _, _) = ctx.sequence_nlm(hf, k=0, overlap=False, search=SEARCH, patch=PATCH)
@@ -750,10 +756,10 @@ def main():
             if rank == 0 and world == 1:
                 # the same pipeline over a 64-frame sequence (the length of BASELINE configs[4]): fill, drain and the GPU's
                 # clock ramp after idle (about 2.8 ms per cold start, tools/pipe_idle_ab.py) weigh a quarter as much
-                # exactly SEQ_FRAMES frames whatever --frames is: the F resident frames cycled (the keys say _64)
-                hf = [f.cpu().numpy() for f in frames]
+                # exactly SEQ_FRAMES frames whatever --frames is: the first XF resident frames cycled (the keys say _64)
+                hf = [f.cpu().numpy() for f in frames[:XF]]
                 lf8 = [np.clip(f * 64.0, 0, 255).astype(np.uint8) for f in hf]
-                lf = [lf8[i % F] for i in range(SEQ_FRAMES)]
+                lf = [lf8[i % len(lf8)] for i in range(SEQ_FRAMES)]
                 def passes(fr, **kw):
                     # pass 0 also pays for first use of the larger buffers and is dropped; of the next four the MEDIAN is
                     # reported, with the spread beside it -- this figure moved 2480-3100 between boxes and runs in rounds
@@ -765,7 +771,7 @@ def main():
                             "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3),
                             "Mpixel/s_min_max_of_4_passes": [round(len(fr) * NPIX / 1e3 / rows[-1][0], 1), round(len(fr) * NPIX / 1e3 / rows[0][0], 1)]}
                 also["pipeline_pcie_inclusive_ldr_64"] = passes(lf, out_u8=True)
-                hf = [hf[i % F] for i in range(SEQ_FRAMES)]
+                hf = [hf[i % len(hf)] for i in range(SEQ_FRAMES)]
                 also["pipeline_pcie_inclusive_64"] = passes(hf)
 
         guarded("pipeline_long", extra_pipeline_long)

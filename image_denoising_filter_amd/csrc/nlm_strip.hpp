@@ -1,6 +1,6 @@
 // nlm_strip.hpp -- the NLM strip kernel (see nlm.hip for the algorithm) and its launcher, shared by the translation units that
 // instantiate it: nlm.hip (the two tuned windows, the per-pixel fallback, the C-ABI), nlm_rt.hip (any search window, patches up to 9x9,
-// strips of eight rows) and nlm_rt4.hip (patches of 10x10 .. 16x16, strips of four rows).  Three files so that the 126 instantiations
+// strips of eight rows) and nlm_rt4.hip (patches of 10x10 .. 16x16, strips of four rows).  Three files so that the 134 instantiations
 // compile in parallel.
 #pragma once
 #include "common.hpp"

@@ -101,6 +101,8 @@ _SIGNATURES = {
     "mid_comm_create": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.c_int, c_void_pp]),
     "mid_comm_create_all": (ctypes.c_int, [c_void_pp, ctypes.c_int, c_void_pp]),
     "mid_comm_destroy": (ctypes.c_int, [_P]),
+    "mid_comm_abort": (ctypes.c_int, [_P]),
+    "mid_comm_reserve": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.c_int]),
     "mid_comm_rank": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mid_comm_loopback": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
     "mid_nlm_temporal_sharded": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), c_void_pp, ctypes.c_int, ctypes.c_int, c_void_pp, _P]),

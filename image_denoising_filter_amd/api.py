@@ -400,6 +400,14 @@ class Comm:
     def __exit__(self, *exc):
         self.close()
 
+    def abort(self):
+        """ncclCommAbort: the way out of a collective a rank could not enter; the handle then only accepts close()."""
+        _check(lib.mid_comm_abort(self.handle), "mid_comm_abort")
+
+    def reserve(self, max_frame_bytes, k):
+        """Allocate the 2k halo receive buffers up front (mid_comm_reserve)."""
+        _check(lib.mid_comm_reserve(self.handle, int(max_frame_bytes), int(k)), "mid_comm_reserve")
+
     def loopback(self, src_ptr, dst_ptr, nbytes, stream=None):
         _check(lib.mid_comm_loopback(self.handle, src_ptr, dst_ptr, nbytes, stream), "mid_comm_loopback")
 

@@ -23,7 +23,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
+#include <condition_variable>
 #include <iostream>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -393,6 +395,19 @@ public:
         std::vector<mid_comm *> comms(G, nullptr);
         struct CommGuard { std::vector<mid_comm *> &v; ~CommGuard() { for (auto c : v) if (c) (void)mid_comm_destroy(c); } } cguard{comms};
         if (opt.halo_rccl) MID_CHECK(mid_comm_create_all(ctxs.data(), G, comms.data()));
+        // all ranks report whether their local set-up succeeded; arrive() returns true only if every one of them did
+        struct Rendezvous {
+            std::mutex m; std::condition_variable cv; int arrived = 0; const int n; bool ok = true;
+            explicit Rendezvous(int n_) : n(n_) {}
+            bool arrive(bool mine)
+            {
+                std::unique_lock<std::mutex> l(m);
+                ok = ok && mine;
+                if (++arrived == n) cv.notify_all();
+                else cv.wait(l, [&] { return arrived == n; });
+                return ok;
+            }
+        } rendezvous(G);
         const auto t0 = std::chrono::steady_clock::now();
         for (int g = 0; g < G; ++g)
             workers.emplace_back([&, g] {
@@ -402,36 +417,52 @@ public:
                         // GPU-resident variant: the block is uploaded once and stays in HBM; the k frames on either side come
                         // from the neighbouring devices over xGMI (ncclSend/ncclRecv, one group) while the interior frames are
                         // being filtered; no frame is uploaded twice.  Every rank calls in, also one that owns no frame.
+                        // mid_nlm_temporal_sharded is collective, so the ranks first finish everything that can fail locally
+                        // (buffers, uploads, timers, the halo receive buffers) and AGREE that all of them did; if one did not,
+                        // no rank enters the exchange.  A failure after that point aborts every communicator, so that ranks
+                        // already waiting for the failed one return with an error instead of hanging.
                         mid_ctx *ctx = ctxs[g];
                         struct Dev { mid_ctx *c; std::vector<void *> p; ~Dev() { for (auto q : p) if (q) (void)mid_free(c, q); } } din{ctx, {}}, dout{ctx, {}};
-                        mid_timer *tk = nullptr, *tc = nullptr;
-                        MID_CHECK(mid_timer_create(ctx, &tk));
-                        MID_CHECK(mid_timer_create(ctx, &tc));
-                        struct TG { mid_timer *a, *b; ~TG() { (void)mid_timer_destroy(a); (void)mid_timer_destroy(b); } } tg{tk, tc};
-                        MID_CHECK(mid_timer_tick(tc, nullptr));
-                        for (int i = 0; i < count; ++i) {
-                            void *d = nullptr;
-                            MID_CHECK(mid_alloc(ctx, in_bytes, &d)); din.p.push_back(d);
-                            MID_CHECK(mid_memcpy_h2d(ctx, d, in[start + i], in_bytes, nullptr));
-                            MID_CHECK(mid_alloc(ctx, (size_t)w * h * 16, &d)); dout.p.push_back(d);
-                        }
-                        MID_CHECK(mid_timer_tock(tc, nullptr));
-                        MID_CHECK(mid_timer_tick(tk, nullptr));
-                        MID_CHECK(mid_nlm_temporal_sharded(comms[g], &p, din.p.data(), n, k, (mid_pixel *const *)dout.p.data(), nullptr));
-                        MID_CHECK(mid_timer_tock(tk, nullptr));
-                        void *u8 = nullptr;
-                        if (!hdr && count) { MID_CHECK(mid_alloc(ctx, out_bytes, &u8)); din.p.push_back(u8); }
-                        for (int i = 0; i < count; ++i) {
-                            if (hdr) MID_CHECK(mid_memcpy_d2h(ctx, pin.outs[start + i], dout.p[i], out_bytes, nullptr));
-                            else {   // GetImageFromGPU's u8 conversion (:97-103) on the device, then a quarter of the bytes come back
-                                MID_CHECK(mid_pack_u8(ctx, (const float *)dout.p[i], (size_t)w * h * 4, (uint8_t *)u8, nullptr));
-                                MID_CHECK(mid_memcpy_d2h(ctx, pin.outs[start + i], u8, out_bytes, nullptr));
+                        struct TG { mid_timer *a = nullptr, *b = nullptr; ~TG() { (void)mid_timer_destroy(a); (void)mid_timer_destroy(b); } } tg;
+                        bool ready = false;
+                        try {
+                            MID_CHECK(mid_timer_create(ctx, &tg.a));
+                            MID_CHECK(mid_timer_create(ctx, &tg.b));
+                            MID_CHECK(mid_timer_tick(tg.b, nullptr));
+                            for (int i = 0; i < count; ++i) {
+                                void *d = nullptr;
+                                MID_CHECK(mid_alloc(ctx, in_bytes, &d)); din.p.push_back(d);
+                                MID_CHECK(mid_memcpy_h2d(ctx, d, in[start + i], in_bytes, nullptr));
+                                MID_CHECK(mid_alloc(ctx, (size_t)w * h * 16, &d)); dout.p.push_back(d);
                             }
+                            if (!hdr && count) { void *u8 = nullptr; MID_CHECK(mid_alloc(ctx, out_bytes, &u8)); din.p.push_back(u8); }
+                            MID_CHECK(mid_comm_reserve(comms[g], in_bytes, k));
+                            MID_CHECK(mid_timer_tock(tg.b, nullptr));
+                            MID_CHECK(mid_stream_sync(ctx, nullptr));
+                            ready = true;
+                        } catch (const std::exception &e) { errors[g] = e.what(); }
+                        if (!rendezvous.arrive(ready)) return;          // (the rank that failed has recorded why)
+                        try {
+                            mid_timer *tk = tg.a, *tc = tg.b;
+                            MID_CHECK(mid_timer_tick(tk, nullptr));
+                            MID_CHECK(mid_nlm_temporal_sharded(comms[g], &p, din.p.data(), n, k, (mid_pixel *const *)dout.p.data(), nullptr));
+                            MID_CHECK(mid_timer_tock(tk, nullptr));
+                            void *u8 = (!hdr && count) ? din.p.back() : nullptr;
+                            for (int i = 0; i < count; ++i) {
+                                if (hdr) MID_CHECK(mid_memcpy_d2h(ctx, pin.outs[start + i], dout.p[i], out_bytes, nullptr));
+                                else {   // GetImageFromGPU's u8 conversion (:97-103) on the device, then a quarter of the bytes come back
+                                    MID_CHECK(mid_pack_u8(ctx, (const float *)dout.p[i], (size_t)w * h * 4, (uint8_t *)u8, nullptr));
+                                    MID_CHECK(mid_memcpy_d2h(ctx, pin.outs[start + i], u8, out_bytes, nullptr));
+                                }
+                            }
+                            MID_CHECK(mid_stream_sync(ctx, nullptr));
+                            float ms = 0.f;
+                            MID_CHECK(mid_timer_ms(tk, &ms)); kern[g] = ms;
+                            MID_CHECK(mid_timer_ms(tc, &ms)); copy[g] = ms;
+                        } catch (const std::exception &e) {
+                            errors[g] = e.what();
+                            for (auto c : comms) if (c) (void)mid_comm_abort(c);
                         }
-                        MID_CHECK(mid_stream_sync(ctx, nullptr));
-                        float ms = 0.f;
-                        MID_CHECK(mid_timer_ms(tk, &ms)); kern[g] = ms;
-                        MID_CHECK(mid_timer_ms(tc, &ms)); copy[g] = ms;
                         return;
                     }
                     if (count == 0) return;

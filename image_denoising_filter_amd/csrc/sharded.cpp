@@ -18,8 +18,17 @@
 //
 // RCCL is bound at RUN time (dlopen of librccl.so.1 on the first mid_comm_* call): the library itself has no link-time
 // dependency on it, single-GPU users never load it, and inside a PyTorch process the dlopen resolves to the copy torch
-// has already mapped (same SONAME), so there is one RCCL per process.
+// has already mapped (same SONAME), so there is one RCCL per process.  MID_RCCL_LIBRARY=<path or soname>, read once on
+// that first call, names the library to load instead of the default search (a site's own RCCL build); a library that
+// cannot be loaded makes every mid_comm_* call return MID_ERR_UNSUPPORTED.
+//
+// mid_nlm_temporal_sharded is a COLLECTIVE: every rank must enter the exchange or none.  Everything that can fail
+// locally -- argument checks, the stream rule, receive-buffer allocation -- therefore happens before the first RCCL
+// call, and a rank that fails there has not touched the wire; its peers are then waiting for it, and the caller must
+// abort (mid_comm_abort) or destroy the communicator on every rank.
 #include "common.hpp"
+#include <atomic>
+#include <cstdlib>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <string>
@@ -35,6 +44,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -47,16 +57,24 @@ Rccl &rccl()
 {
     static Rccl r = [] {
         Rccl x;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        const char *forced = getenv("MID_RCCL_LIBRARY");
+        std::vector<const char *> names;
+        if (forced && *forced) names = {forced};
+        else names = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *name : names) {
             x.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (x.so) break;
+            const char *e = dlerror();          // (one call: dlerror() clears the message it returns)
+            x.why += std::string(x.why.empty() ? "" : "; ") + "cannot load " + name + ": " + (e ? e : "?");
         }
-        if (!x.so) { x.why = std::string("cannot load librccl.so.1: ") + (dlerror() ? dlerror() : "?"); return x; }
+        if (!x.so) return x;
+        x.why.clear();
         auto sym = [&](const char *n) { void *p = dlsym(x.so, n); if (!p && x.why.empty()) x.why = std::string("librccl lacks ") + n; return p; };
         x.GetUniqueId = (decltype(x.GetUniqueId))sym("ncclGetUniqueId");
         x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
         x.CommInitAll = (decltype(x.CommInitAll))sym("ncclCommInitAll");
         x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy");
+        x.CommAbort = (decltype(x.CommAbort))sym("ncclCommAbort");
         x.GroupStart = (decltype(x.GroupStart))sym("ncclGroupStart");
         x.GroupEnd = (decltype(x.GroupEnd))sym("ncclGroupEnd");
         x.Send = (decltype(x.Send))sym("ncclSend");
@@ -167,10 +185,15 @@ struct mid_comm {
     int rank = 0, world = 1;
     hipStream_t xs = nullptr;               // exchange stream
     hipEvent_t e0 = nullptr, e1 = nullptr, x0 = nullptr;
+    hipEvent_t done = nullptr;              // end of the last sharded call's launches, on the stream it was issued on
+    hipStream_t last_stream = nullptr;      // that stream (valid while has_last)
+    bool has_last = false;
     std::vector<void *> halo;               // device buffers for received frames, grown on demand
     size_t halo_bytes = 0;                  // size of each
+    std::vector<void *> retired;            // buffers of an earlier, smaller frame size: freed once `done` has passed
     size_t last_recv = 0, last_sent = 0;
     bool timed = false;
+    std::atomic<bool> aborted{false};       // set by mid_comm_abort, possibly from another thread than the one inside a call
 };
 
 static int comm_finish_create(mid_comm *c)
@@ -179,6 +202,25 @@ static int comm_finish_create(mid_comm *c)
     MID_HIP(hipEventCreateWithFlags(&c->e0, hipEventDisableTiming));
     MID_HIP(hipEventCreate(&c->e1));
     MID_HIP(hipEventCreate(&c->x0));
+    MID_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    return MID_OK;
+}
+
+// Receive buffers: `n` of `bytes` each.  A larger frame size retires the old buffers instead of freeing them -- launches
+// of the previous call may still read them, and both hipFree and a device-wide synchronisation would stall the caller's
+// streams mid-call; they are released once that call's `done` event has passed (or with the communicator).
+static int reserve_halo(mid_comm *c, size_t bytes, size_t n)
+{
+    if (!c->retired.empty() && (!c->has_last || hipEventQuery(c->done) == hipSuccess)) {
+        for (void *q : c->retired) (void)hipFree(q);
+        c->retired.clear();
+    }
+    if (bytes > c->halo_bytes) {
+        c->retired.insert(c->retired.end(), c->halo.begin(), c->halo.end());
+        c->halo.clear();
+        c->halo_bytes = bytes;
+    }
+    while (c->halo.size() < n) { void *q = nullptr; MID_HIP(hipMalloc(&q, c->halo_bytes)); c->halo.push_back(q); }
     return MID_OK;
 }
 
@@ -273,14 +315,37 @@ extern "C" int mid_comm_destroy(mid_comm *c)
     if (!c) return MID_OK;
     (void)hipSetDevice(c->ctx->device);
     if (c->xs) (void)hipStreamSynchronize(c->xs);
+    if (c->has_last && c->done) (void)hipEventSynchronize(c->done);      // launches that still read the receive buffers
     for (void *p : c->halo) (void)hipFree(p);
-    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    for (void *p : c->retired) (void)hipFree(p);
+    if (c->comm && !c->aborted) (void)rccl().CommDestroy(c->comm);
     if (c->e0) (void)hipEventDestroy(c->e0);
     if (c->e1) (void)hipEventDestroy(c->e1);
     if (c->x0) (void)hipEventDestroy(c->x0);
+    if (c->done) (void)hipEventDestroy(c->done);
     if (c->xs) (void)hipStreamDestroy(c->xs);
     delete c;
     return MID_OK;
+}
+
+// ncclCommAbort: tears this rank's connections down WITHOUT waiting for outstanding operations -- the way out when a rank
+// has failed before (or inside) a collective call and its peers would otherwise wait for it for ever.  The handle stays
+// valid for mid_comm_destroy only; every other call on it returns MID_ERR_INVALID.
+extern "C" int mid_comm_abort(mid_comm *c)
+{
+    MID_REQUIRE(c != nullptr, "comm_abort: comm is NULL");
+    if (c->aborted.exchange(true)) return MID_OK;
+    (void)hipSetDevice(c->ctx->device);
+    if (c->comm) MID_NCCL(rccl().CommAbort(c->comm));      // (frees the communicator: mid_comm_destroy skips ncclCommDestroy)
+    return MID_OK;
+}
+
+extern "C" int mid_comm_reserve(mid_comm *c, size_t max_frame_bytes, int k)
+{
+    MID_REQUIRE(c && !c->aborted && max_frame_bytes > 0 && k >= 0, "comm_reserve: bad argument");
+    Bind b(c->ctx, nullptr);
+    if (b.rc) return b.rc;
+    return reserve_halo(c, max_frame_bytes, c->world > 1 ? 2 * (size_t)k : 0);
 }
 
 extern "C" int mid_comm_rank(mid_comm *c, int *rank, int *world)
@@ -296,6 +361,7 @@ extern "C" int mid_comm_rank(mid_comm *c, int *rank, int *world)
 extern "C" int mid_comm_loopback(mid_comm *c, const void *src, void *dst, size_t bytes, void *stream)
 {
     MID_REQUIRE(c && src && dst && bytes > 0, "comm_loopback: bad argument");
+    MID_REQUIRE(!c->aborted, "comm_loopback: the communicator was aborted");
     Bind b(c->ctx, stream);
     if (b.rc) return b.rc;
     MID_HIP(hipEventRecord(c->e0, b.s));
@@ -315,8 +381,20 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
                                         mid_pixel *const *out, void *stream)
 {
     MID_REQUIRE(c && p && n_frames >= 1 && k >= 0, "nlm_temporal_sharded: bad argument");
+    MID_REQUIRE(!c->aborted, "nlm_temporal_sharded: the communicator was aborted");
     Bind b(c->ctx, stream);
     if (b.rc) return b.rc;
+    // Stream rule.  The receive buffers, e0/e1 and the exchange stream are reused from call to call, ordered behind the
+    // previous call's launches only through the stream both calls are issued on.  A call on ANOTHER stream is accepted
+    // only once the previous call has finished (the caller synchronised its stream, or the work simply is done);
+    // otherwise it would race on the halo buffers silently.
+    if (c->has_last && c->last_stream != b.s) {
+        const hipError_t q = hipEventQuery(c->done);
+        MID_REQUIRE(q != hipErrorNotReady,
+                    "nlm_temporal_sharded: the previous call on this communicator was issued on another stream and is still in flight; "
+                    "use one stream per communicator or synchronise the earlier stream first (mid_stream_sync)");
+        MID_HIP(q);
+    }
     int start, count;
     block_of(n_frames, c->world, c->rank, start, count);
     MID_REQUIRE(count == 0 || (block && out), "nlm_temporal_sharded: NULL table");
@@ -329,15 +407,9 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
     c->last_recv = rv.size() * frame_bytes; c->last_sent = sd.size() * frame_bytes; c->timed = false;
 
     // receive buffers (kept across calls; a call's receives are ordered after the previous call's last readers through
-    // e0: calls on one communicator must be issued on one stream, or be separated by a synchronisation)
-    if (frame_bytes > c->halo_bytes) {
-        // (rare: the frame size grew between calls.  The old buffers may still be read by launches of the previous call.)
-        if (!c->halo.empty()) MID_HIP(hipDeviceSynchronize());
-        for (void *q : c->halo) (void)hipFree(q);
-        c->halo.clear();
-        c->halo_bytes = frame_bytes;
-    }
-    while (c->halo.size() < rv.size()) { void *q = nullptr; MID_HIP(hipMalloc(&q, c->halo_bytes)); c->halo.push_back(q); }
+    // e0 on the one stream the stream rule above enforces).  Last local step that can fail: nothing below this line
+    // returns before the exchange has been issued, except an RCCL error itself.
+    if (int rc = reserve_halo(c, frame_bytes, rv.size())) return rc;
 
     if (!rv.empty() || !sd.empty()) {
         MID_HIP(hipEventRecord(c->e0, b.s));                       // the block's frames (and the halo buffers' last readers) are done
@@ -353,7 +425,11 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
         MID_HIP(hipEventRecord(c->e1, c->xs));
         c->timed = true;
     }
-    if (count == 0) return MID_OK;
+    if (count == 0) {
+        MID_HIP(hipEventRecord(c->done, b.s));
+        c->last_stream = b.s; c->has_last = true;
+        return MID_OK;
+    }
 
     std::vector<Launch> plan;
     launch_plan(n_frames, c->world, k, c->rank, plan);
@@ -374,6 +450,8 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
             if (int rc = mid_nlm_temporal(c->ctx, p, tbl.data(), (int)tbl.size(), k, L.first, L.count, out + L.off, b.s)) return rc;
         }
     }
+    MID_HIP(hipEventRecord(c->done, b.s));
+    c->last_stream = b.s; c->has_last = true;
     return MID_OK;
 }
 

@@ -230,10 +230,24 @@ int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const void *host_t
  *   [first, first+count), stored at block-relative out_offset.  `cap` = capacity of the caller's arrays.
  * mid_comm_unique_id + mid_comm_create: one process per GPU (rank 0 makes the id and hands it to the others out of
  *   band -- a file, MPI, torch.distributed); mid_comm_create_all: one process, one context per device.
+ *   RCCL is looked up as librccl.so.1 / librccl.so / /opt/rocm/lib/librccl.so.1; the environment variable
+ *   MID_RCCL_LIBRARY (read once, on the first mid_comm_* call) names the library to load instead.
  * mid_nlm_temporal_sharded: `block` = this rank's `count` device frames in order, `out` = `count` device outputs.
- *   Asynchronous on `stream`; every rank of the communicator must call it with the same n_frames, k and frame size.
- *   Calls on one communicator must be issued on one stream (the receive buffers are reused).  Results are bit-identical
- *   to one mid_nlm_temporal over the whole sequence (same kernels, same tile shape).
+ *   Asynchronous on `stream`.  COLLECTIVE: every rank of the communicator must call it, with the same n_frames, k and
+ *   frame size -- also a rank that owns no frame.  Everything that can fail locally (arguments, the stream rule below,
+ *   receive-buffer allocation) is checked before the first RCCL call, so a rank that returns an error there has not
+ *   entered the exchange; its peers then wait for it, and the caller must mid_comm_abort (or destroy) the communicator
+ *   on EVERY rank -- there is no other way out of a half-entered collective.
+ *   Stream rule: the receive buffers are reused from call to call, ordered only through the stream the calls are issued
+ *   on.  A call on a different stream than the previous one returns MID_ERR_INVALID unless the previous call's work has
+ *   finished (e.g. after mid_stream_sync on the earlier stream).
+ *   Results are the bits of one mid_nlm_temporal over the whole sequence by construction (same kernels, same tile
+ *   shape, same frame tables: tests/test_shard_native_plan.py); executed on hardware for world = 1 only so far -- an
+ *   N >= 2 run is gated by bench.py's `bit_identical_to_single_launch_per_rank`.
+ * mid_comm_reserve: allocates the 2k receive buffers for frames of up to max_frame_bytes up front, so that no sharded
+ *   call allocates (optional; otherwise they are allocated on first use and retired, not freed, when the frame size grows).
+ * mid_comm_abort: ncclCommAbort -- tears the rank's connections down without waiting for outstanding operations; the
+ *   handle then only accepts mid_comm_destroy.
  * mid_comm_loopback: a send+receive addressed to this very rank (the exchange's call pattern without the wire).
  * mid_comm_last_exchange: bytes received/sent by the last sharded call and (waits for it) the exchange's duration. */
 typedef struct mid_comm mid_comm;
@@ -246,6 +260,8 @@ int mid_comm_unique_id(uint8_t id[MID_COMM_ID_BYTES]);
 int mid_comm_create(mid_ctx *ctx, const uint8_t id[MID_COMM_ID_BYTES], int rank, int world, mid_comm **out);
 int mid_comm_create_all(mid_ctx *const *ctxs, int world, mid_comm **out /* world entries */);
 int mid_comm_destroy(mid_comm *comm);
+int mid_comm_abort(mid_comm *comm);
+int mid_comm_reserve(mid_comm *comm, size_t max_frame_bytes, int k);
 int mid_comm_rank(mid_comm *comm, int *rank, int *world);
 int mid_comm_loopback(mid_comm *comm, const void *src, void *dst, size_t bytes, void *stream);
 int mid_nlm_temporal_sharded(mid_comm *comm, const mid_nlm_params *p, const void *const *block /* count device frames */,

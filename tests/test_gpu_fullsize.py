@@ -114,6 +114,29 @@ def test_half_shape_of_a_small_launchs_last_round_is_bit_identical(ctx, frame, c
     assert np.array_equal(t1, ctx.normalize(Wt))
 
 
+@pytest.mark.parametrize("h", [1083, 1086])
+def test_half_shape_on_a_ragged_last_tile_row(ctx, frame, h):
+    """Heights that are not a multiple of 8: in the last tile row a strip is cut after 3 rows (1083 % 8 = 3: the HALF
+    shape's upper-half wave writes 3 rows, its lower-half wave none) or after 6 (1086: the lower-half wave writes 2 of
+    its 4).  Still 34 x 34 tiles = 1156 workgroups = 2 full rounds + 132, so the tail rule fires exactly as at 1080 rows,
+    and the XCD remap puts the first half of the bottom tile row into the standard shape and the second half into the
+    HALF shape (on a 256-CU device).  Same bits as the 3-frame launch (no tail) and as accumulate + normalize, and every
+    pixel within tolerance of the float64 checker."""
+    import f64_checker as f64
+    rng = np.random.default_rng(h)
+    big = np.concatenate([frame, frame[:16]], 0)[:h]
+    fr = [(big * 0.25 * rng.gamma(16.0, 1 / 16.0, (h, W, 1))).astype(np.float32) for _ in range(3)]
+    for cfg in (dict(search=(-10, 11), patch=(-3, 4)), dict(search=(-7, 7), patch=(-3, 3))):
+        batch = ctx.nlm_temporal(fr, k=0, **cfg)
+        single = ctx.nlm_temporal([fr[2]], k=0, **cfg)[0]
+        assert np.array_equal(batch[2], single)
+        unfused = ctx.normalize(ctx.nlm_accum(fr[2], fr[2], np.zeros((h, W, 8), np.float32), 0.5, **cfg))
+        assert np.array_equal(single, unfused)
+        ref = f64.nlm_temporal_output([fr[2]], 0, 0, 0.5, cfg["search"], cfg["patch"])
+        assert rel_err(single, ref) < 2e-5
+        assert rel_err(single[-8:], ref[-8:]) < 2e-5 and single[-8:].min() > 0
+
+
 def test_constant_frame_properties(ctx):
     img = np.tile(np.float32([0.25, 0.5, 2.0, 1.0]), (H, W, 1))
     out = ctx.bilateral(img, 8, 2.0, 0.2)

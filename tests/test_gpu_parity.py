@@ -100,6 +100,13 @@ NLM_CFGS = {"ref": dict(search=(-7, 7), patch=(-3, 3)), "bench": dict(search=(-1
             "naive": dict(search=(-2, 3), patch=(-1, 3))}             # lopsided 4x4 patch: no strip instantiation -> one-thread-per-pixel fallback
 
 
+def _nlm_f64(t, nb, W0, hparam, search, patch):
+    """W0 + one dispatch's sums from the float64 NumPy restatement (tests/np_reference.py): [h, w, 5] float64."""
+    import np_reference as npr
+    num, den = npr.nlm_sums(t, nb, hparam, search, patch)
+    return np.concatenate([num, den[..., None]], -1) + np.asarray(W0, np.float64)[..., :5]
+
+
 def _nlm_pair(rng, h, w, scale=0.25):
     t = (synth_hdr(rng, h, w) * scale).astype(np.float32)
     nb = (t * rng.gamma(16.0, 1 / 16.0, (h, w, 1))).astype(np.float32)
@@ -113,10 +120,13 @@ def test_nlm_accum(ctx, cfg):
     t, nb = _nlm_pair(rng, h, w)
     W0 = rng.random((h, w, 8), dtype=np.float32)     # the dispatch ADDS to whatever W holds
     Wg, Wo = ctx.nlm_accum(t, nb, W0, 0.5, **NLM_CFGS[cfg]), oracle.nlm_accum(t, nb, W0, 0.5, **NLM_CFGS[cfg])
-    # 625 offsets x 5x5 patch: measured against float64, the oracle (reference loop order) and the kernel are
-    # EACH within 1.3e-5 of the exact sums, on opposite sides -- two fp32 evaluations can differ by 2.6e-5.
-    tol = 5e-5 if cfg == "rt5" else NLM_TOL
-    assert rel_err(Wg[..., :5], Wo[..., :5]) < tol
+    if cfg == "rt5":
+        # 625 offsets x 5x5 patch: oracle.c (fp32, the shader's loop order) and the kernel (fp32, block sums) are two
+        # fp32 evaluations of sums of 625 terms and can sit on opposite sides of the exact value, so each is held
+        # against the float64 restatement at the SAME tolerance instead of against the other at a wider one.
+        Wo = _nlm_f64(t, nb, W0, 0.5, **NLM_CFGS[cfg])
+        assert rel_err(oracle.nlm_accum(t, nb, W0, 0.5, **NLM_CFGS[cfg])[..., :5], Wo) < NLM_TOL
+    assert rel_err(Wg[..., :5], Wo[..., :5]) < NLM_TOL
     assert np.array_equal(Wg[..., 5:], W0[..., 5:]), "std430 padding is never written"
 
 
@@ -378,8 +388,8 @@ def test_runtime_range_kernel_small_then_large_window(ctx):
     nb = np.clip(t + 0.05 * rng.standard_normal((40, 70, 4)), 0, 1).astype(np.float32)
     for search in ((-2, 3), (-14, 15), (-3, 4), (-20, 21)):
         got = ctx.nlm_accum(t, nb, Z(40, 70), 0.5, search=search, patch=(-2, 3))
-        ref = oracle.nlm_accum(t, nb, Z(40, 70), 0.5, search=search, patch=(-2, 3))
-        assert rel_err(got[..., :5], ref[..., :5]) < 5e-5, search
+        # up to 1681 offsets: held against the float64 restatement (two fp32 evaluations may differ by twice the tolerance)
+        assert rel_err(got[..., :5], _nlm_f64(t, nb, Z(40, 70), 0.5, search, (-2, 3))) < NLM_TOL, search
 
 
 @pytest.mark.parametrize("search,patch", [((-12, 13), (-3, 4)), ((-15, 16), (-1, 2)), ((-11, 12), (-2, 3)), ((-17, 18), (-2, 3))])
@@ -479,8 +489,11 @@ def test_nlm_unusual_windows(ctx, search, patch):
     rng = np.random.default_rng(abs(search[0]) * 31 + patch[1])
     t, nb = synth_hdr(rng, 29, 71) * 0.3, synth_hdr(rng, 29, 71) * 0.3
     got = ctx.nlm_accum(t, nb, Z(29, 71), 0.45, search, patch)
-    ref = oracle.nlm_accum(t, nb, Z(29, 71), 0.45, search, patch)
-    assert rel_err(got, ref) < 5e-5, (search, patch)
+    # float64 (see test_nlm_accum, "rt5"): oracle.c adds a window's terms one after the other in fp32 like the shader, and at
+    # 33x33 offsets that sum alone is 2.5e-5 away from the exact value -- the kernel is held to 2e-5 of the exact value instead
+    ref = _nlm_f64(t, nb, Z(29, 71), 0.45, search, patch)
+    assert rel_err(got[..., :5], ref) < NLM_TOL, (search, patch)
+    assert not got[..., 5:].any()
 
 
 # ---- batched plain bilateral ------------------------------------------------------------------------

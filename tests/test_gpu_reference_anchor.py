@@ -94,3 +94,35 @@ def test_a4_nlm_on_a_linear_ramp_is_the_anchored_bilateral(ctx, patch):
     # and the fused form: normalize divides by (0.001 + sum w)
     out = ctx.nlm_temporal([img], k=0, hparam=hp, search=(-R, R + 1), patch=patch)[0]
     assert rel_err(out[m:-m, m:-m], bil[m:-m, m:-m].astype(np.float64) * (sw / (sw + 0.001))[..., None]) < 2e-5
+
+
+@pytest.mark.parametrize("R", [10, 8])
+def test_a4_nlm_with_a_1x1_patch_on_a_noisy_1080p_frame_is_the_anchored_bilateral(ctx, R):
+    """The ramp identity above needs a linear image; this one holds on ANY image: with a 1x1 patch (patch range [0,1))
+    nonlocal.comp's distance is the plain colour difference of the two texels, d(p,s) = |I(p) - I(p+s)|^2_rgb
+    (nonlocal.comp:42-52 with one tap), so its weight exp(-d/h^2) (:55) is bialteral.comp's range weight
+    exp(-d / (2 sigma_c^2)) (bialteral.comp:60-65) with sigma_c = h / sqrt(2), and sigma_s -> infinity removes the
+    spatial term (exp(-r^2 / 2e12) rounds to 1 in fp32 for r <= 15).  Both shaders sum the 4-channel colour of the
+    (2R+1)^2 texels of the window (nonlocal.comp:36-38,56 with the closed range [-R, R+1); bialteral.comp:51-72), and
+    both give an out-of-image texel the value vec4(0) AND its weight -- so the identity holds on the WHOLE frame,
+    borders included, on noisy data where the weights are all different.  The bilateral kernel is anchored to output
+    of the reference's own loop (tests above), so this pins through a1: the walk over the search window (every offset
+    visited once, none transposed: the image is not symmetric), the zero-texel border policy, the exponent, the
+    4-channel weighted sum and the 0.001 norm bias (nonlocal.comp:32) -- on a full-size frame."""
+    from conftest import synth_hdr
+    H, W, hp = 1080, 1920, 0.5
+    rng = np.random.default_rng(77 + R)
+    img = (synth_hdr(rng, H, W, 6.0) * 0.25 * rng.gamma(16.0, 1 / 16.0, (H, W, 1))).astype(np.float32)
+    img[..., 3] = rng.random((H, W), dtype=np.float32)               # alpha is carried like colour by both shaders
+    Wn = ctx.nlm_accum(img, img, np.zeros((H, W, 8), np.float32), hp, (-R, R + 1), (0, 1))
+    bil = ctx.bilateral(img, R, 1e6, hp / np.sqrt(2.0), "texture").astype(np.float64)
+    sw = Wn[..., 4].astype(np.float64) - 0.001                        # >= 1: the zero offset has weight exp(0)
+    assert sw.min() > 0.999
+    got = Wn[..., :4].astype(np.float64) / sw[..., None]
+    assert rel_err(got, bil) < 2e-5
+    # the fused form divides by (0.001 + sum w): mid_nlm_temporal's output is the bilateral's, scaled by sw / (sw + 0.001)
+    out = ctx.nlm_temporal([img], k=0, hparam=hp, search=(-R, R + 1), patch=(0, 1))[0]
+    assert rel_err(out, bil * (sw / (sw + 0.001))[..., None]) < 2e-5
+    # not vacuous: the filter moved the frame, and the borders are darker than the interior's mean ratio
+    assert rel_err(out, img) > 1e-2
+    assert (out[0, :, 0] / np.maximum(img[0, :, 0], 1e-6)).mean() < (out[540, :, 0] / np.maximum(img[540, :, 0], 1e-6)).mean()

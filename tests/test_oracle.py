@@ -96,6 +96,28 @@ def test_nlm_vs_float64(search, patch):
     assert rel_err(W[..., :4], num) < 2e-5 and rel_err(W[..., 4], den) < 2e-5
 
 
+@pytest.mark.parametrize("search,patch", [((-7, 7), (-3, 3)), ((-10, 11), (-3, 4)), ((-3, 6), (-2, 3)), ((-4, 5), (0, 1))])
+def test_torch_float64_checker_agrees_with_the_oracle_and_the_numpy_restatement(search, patch):
+    """tests/f64_checker.py (difference image + box sums, torch float64) is what the GPU suite holds WHOLE 1080p frames
+    against (test_gpu_nlm_fullframe.py); here it is held against oracle.c (fp32, shader loops) and against
+    np_reference.py (float64, tap loop) on a small two-frame case: three statements of nonlocal.comp:28-63 written
+    three different ways must agree -- the float64 pair to float64 rounding, oracle.c to the NLM tolerance."""
+    import f64_checker as f64
+    rng = np.random.default_rng(12)
+    h, w = 19, 26
+    t = (synth_hdr(rng, h, w) * 0.25).astype(np.float32)
+    nb = (t * rng.gamma(16.0, 1 / 16.0, (h, w, 1))).astype(np.float32)
+    num, den = f64.nlm_sums(t, [t, nb], 0.5, search, patch)
+    num, den = num.cpu().numpy(), den.cpu().numpy()
+    n1, d1 = npr.nlm_sums(t, t, 0.5, search, patch)
+    n2, d2 = npr.nlm_sums(t, nb, 0.5, search, patch)
+    assert rel_err(num, n1 + n2) < 1e-12 and rel_err(den, d1 + d2) < 1e-12
+    W = oracle.nlm_accum(t, nb, oracle.nlm_accum(t, t, W0(h, w), 0.5, search, patch), 0.5, search, patch)
+    assert rel_err(W[..., :4], num) < 2e-5 and rel_err(W[..., 4], den) < 2e-5
+    out = f64.nlm_temporal_output([t, nb], 0, 1, 0.5, search, patch)
+    assert rel_err(oracle.normalize(W), out) < 2e-5
+
+
 # ---- properties ---------------------------------------------------------------------------------
 def test_constant_image_is_invariant_in_the_interior():
     img = np.tile(np.array([0.3, 0.6, 0.9, 1.0], np.float32), (30, 34, 1))

@@ -505,23 +505,28 @@ def main():
             res.setdefault("cpu_baseline", None)
             print(json.dumps(res), file=json_out, flush=True)
 
+    in_flight = {"extra": None}
+
     def on_timeout():
-        also["error"] = "extras did not finish within 300 s; line emitted by the watchdog"
+        also["error"] = (f"extras did not finish within 300 s (in flight: {in_flight['extra']}); line emitted by the watchdog, "
+                         "which then ends the process with exit code 3")
         emit()
-        # One rank: nothing below can wait for a peer, so a hang is a fault of this process -> non-zero.  N > 1: the timed
-        # region and its max-over-ranks reduction completed on every rank before any extra started; what can hang below are
-        # the halo-exchange extras, which no builder box (one GPU) could ever run on hardware.  Their failure is recorded in
-        # the line (`also.error`) and must not void the scaling measurement: exit 0 (every rank has this timer).
-        os._exit(3 if world == 1 else 0)
+        # A process that has touched the GPU and is abandoned in the middle of an extra -- possibly inside a collective
+        # whose peers are still waiting -- must not report success, whatever the world size: the headline line above is
+        # complete (the timed region and its max-over-ranks reduction finished on every rank before any extra started),
+        # `also.error` names the extra that was in flight, and the exit code says that this run did not end cleanly.
+        os._exit(3)
     watchdog = threading.Timer(300.0, on_timeout)
     watchdog.daemon = True
     watchdog.start()
 
     def guarded(name, fn):
+        in_flight["extra"] = name
         try:
             fn()
         except Exception as e:          # an extra must never take the measurement down with it
             also[name + "_error"] = f"{type(e).__name__}: {e}"
+        in_flight["extra"] = None
 
     XF = 16                             # frames of the 16-frame side measurements (bilateral batch, short pipelines), whatever --frames is
     if not args.no_extras:

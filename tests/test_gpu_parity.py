@@ -489,10 +489,17 @@ def test_nlm_unusual_windows(ctx, search, patch):
     rng = np.random.default_rng(abs(search[0]) * 31 + patch[1])
     t, nb = synth_hdr(rng, 29, 71) * 0.3, synth_hdr(rng, 29, 71) * 0.3
     got = ctx.nlm_accum(t, nb, Z(29, 71), 0.45, search, patch)
-    # float64 (see test_nlm_accum, "rt5"): oracle.c adds a window's terms one after the other in fp32 like the shader, and at
-    # 33x33 offsets that sum alone is 2.5e-5 away from the exact value -- the kernel is held to 2e-5 of the exact value instead
+    # Held against float64 (see test_nlm_accum, "rt5").  The tolerance 2e-5 is SURVEY.md 8c's figure for the windows it
+    # names (<= 21x21 = 441 offsets); an fp32 sum of N non-negative terms is only good to about N * 2^-24 of its value
+    # (terms below half an ulp of the running sum are dropped one by one), in the shader's own order too: at 33x33 =
+    # 1089 offsets oracle.c, which adds in nonlocal.comp's order, is itself 2.5e-5 from the exact sums on this very
+    # input (the same 1089 fp32 weights added in float64 are 1.4e-7 away), the kernel 3.2e-5.  So beyond 441 offsets
+    # the tolerance grows with the number of terms, for the kernel and for the reference order alike.
+    n_off = (search[1] - search[0]) ** 2
+    tol = NLM_TOL * max(1.0, n_off / 441.0)
     ref = _nlm_f64(t, nb, Z(29, 71), 0.45, search, patch)
-    assert rel_err(got[..., :5], ref) < NLM_TOL, (search, patch)
+    assert rel_err(got[..., :5], ref) < tol, (search, patch)
+    assert rel_err(oracle.nlm_accum(t, nb, Z(29, 71), 0.45, search, patch)[..., :5], ref) < tol, (search, patch)
     assert not got[..., 5:].any()
 
 

@@ -57,6 +57,36 @@ with mid.Comm(ctx, uid, 0, 1) as comm:
         raise SystemExit("short block accepted")
     except ValueError:
         pass
+    # the stream rule: the receive buffers are reused from call to call, ordered only through the stream the calls are
+    # issued on -- a call on ANOTHER stream while the previous one is in flight is refused, after a synchronisation accepted
+    import torch
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    hb, wb, nb = 1080, 1920, 8
+    big_in = [ctx.upload(frame) for _ in range(nb)]
+    big_out = [ctx.alloc(frame.nbytes) for _ in range(nb)]
+    args = ([d.ptr for d in big_in], [d.ptr for d in big_out], wb, hb, nb, 2, 0.5, (-10, 11), (-3, 4), mid.FMT_RGBA32F)
+    comm.reserve(frame.nbytes, 2)
+    comm.nlm_temporal_sharded_dev(*args, stream=sA.cuda_stream)          # 34 frame pairs at ~0.45 ms: still running ...
+    try:
+        comm.nlm_temporal_sharded_dev(*args, stream=sB.cuda_stream)      # ... when this one arrives on the other stream
+        raise SystemExit("a second stream was accepted while the first call was in flight")
+    except mid.MidError as e:
+        assert e.code == 1 and "another stream" in str(e), str(e)
+    comm.nlm_temporal_sharded_dev(*args, stream=sA.cuda_stream)          # the same stream again: fine
+    ctx.sync(sA.cuda_stream)
+    comm.nlm_temporal_sharded_dev(*args, stream=sB.cuda_stream)          # after the synchronisation: fine
+    ctx.sync(sB.cuda_stream)
+    one = ctx.nlm_temporal([frame] * 3, k=2, first=0, count=1, search=(-10, 11), patch=(-3, 4))[0]
+    assert np.array_equal(ctx.download(big_out[0], frame.shape, np.float32), one)
+    rep["stream_rule"] = "refused, then accepted"
+    # abort: the handle then only accepts destroy
+    comm.abort()
+    try:
+        comm.nlm_temporal_sharded_dev(*args)
+        raise SystemExit("an aborted communicator accepted a call")
+    except mid.MidError as e:
+        assert e.code == 1 and "aborted" in str(e), str(e)
+    rep["abort"] = "refused afterwards"
 print("SHARD1 " + json.dumps(rep), flush=True)
 '''
 
@@ -71,6 +101,7 @@ def test_one_rank_communicator_loopback_and_sharded_temporal_nlm(tmp_path):
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("SHARD1 ")][0][7:])
     assert rep["loopback_bytes"] == 1920 * 1080 * 16
     assert rep["last_exchange"] == [0, 0, 0.0]                     # one rank: nothing to exchange
+    assert rep["stream_rule"] == "refused, then accepted" and rep["abort"] == "refused afterwards"
 
 
 @pytest.mark.parametrize("hdr", [True, False])

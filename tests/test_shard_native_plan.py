@@ -70,3 +70,26 @@ def test_argument_errors_and_no_gpu_behaviour():
     assert mid.lib.mid_comm_create(None, None, 0, 1, None) == 1          # NULL context: rejected before RCCL is even loaded
     assert mid.lib.mid_nlm_temporal_sharded(None, None, None, 1, 0, None, None) == 1
     assert mid.lib.mid_comm_destroy(None) == 0
+    assert mid.lib.mid_comm_abort(None) == 1 and mid.lib.mid_comm_reserve(None, 16, 1) == 1
+
+
+def test_a_missing_rccl_is_unsupported_not_a_crash(tmp_path):
+    """RCCL is dlopen'd on the first mid_comm_* call.  When no library can be loaded the call must come back with
+    MID_ERR_UNSUPPORTED and a message naming the attempt (round 3 built that message from a second dlerror() call,
+    which returns NULL: a crash instead of an error code).  MID_RCCL_LIBRARY forces the name; fresh process, because the
+    binding is made once per process."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import ctypes, image_denoising_filter_amd as mid\n"
+            "buf = (ctypes.c_uint8 * 128)()\n"
+            "rc = mid.lib.mid_comm_unique_id(buf)\n"
+            "print(rc, mid.lib.mid_last_error().decode())\n"
+            "rc2 = mid.lib.mid_comm_unique_id(buf)\n"            # and again: the failure is remembered, not retried into a crash
+            "assert rc2 == rc\n")
+    env = dict(__import__("os").environ, MID_RCCL_LIBRARY=str(tmp_path / "no_such_librccl.so"))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rc, msg = r.stdout.strip().split(" ", 1)
+    assert int(rc) == 4, r.stdout                                 # MID_ERR_UNSUPPORTED
+    assert "RCCL is not available" in msg and "no_such_librccl.so" in msg and "cannot load" in msg

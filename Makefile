@@ -24,11 +24,6 @@ $(LIB): $(OBJS)
 EXTRA_nlm.hip := -mllvm -amdgpu-sched-strategy=max-ilp
 EXTRA_nlm_rt.hip := $(EXTRA_nlm.hip)
 EXTRA_nlm_rt4.hip := $(EXTRA_nlm.hip)
-# `make TUNING=1` (after `make clean`) also builds the alternative NLM tile shapes that tools/ab_nlm.py selects
-# with MID_NLM_VARIANT; the shipped library has none of them.
-ifdef TUNING
-EXTRA_nlm.hip += -DMID_NLM_TUNING
-endif
 
 build/%.o: $(CSRC)/% $(CSRC)/common.hpp $(CSRC)/nlm_strip.hpp $(CSRC)/codec/image_io.hpp include/mi_denoise.h
 	@mkdir -p $(dir $@)

@@ -474,7 +474,7 @@ def main():
                    "parallelism": f"frame-sharded x{world}, no data-path collective",
                    **({"process_group": process_group} if process_group else {})},
         "roofline": {
-            "bound": "mfma", "bound_actual": "valu", "achieved": round(flop_px * px_per_launch / avg_launch_s / 1e12, 3),
+            "bound": "valu", "bound_contract_enum": "mfma", "achieved": round(flop_px * px_per_launch / avg_launch_s / 1e12, 3),
             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop_px * px_per_launch / avg_launch_s / 1e12 / PEAK_FP32_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
@@ -482,8 +482,9 @@ def main():
             # spread of the K timed launches (hipEvent pairs on the launch stream, one pair per step)
             "kernel_ms_min": round(min(kernel_ms) / launches_per_step, 4), "kernel_ms_max": round(max(kernel_ms) / launches_per_step, 4),
             **load_utilisation(args.workload),
-            "note": "compute roofline (`bound` keeps the contract's enum; bound_actual says what binds): the kernel is fp32-VALU bound and issues no MFMA; the peak is the fp32 "
-                    "vector peak, which equals the dense f32 MFMA peak on gfx950 (157.3 TFLOP/s). Algorithmic "
+            "note": "compute roofline: the kernel is bound by fp32 vector (VALU) issue and contains no MFMA instruction, so `bound` says "
+                    "\"valu\"; the contract's two-valued enum would file it under its compute entry (`bound_contract_enum`). The peak is "
+                    "the fp32 vector peak, which equals the dense f32 MFMA peak on gfx950 (157.3 TFLOP/s). Algorithmic "
                     f"flops = {flop_note} x px per launch.",
             "hbm": {"achieved_GBs": round(bytes_px * px_per_launch / avg_launch_s / 1e9, 1),
                     "peak_GBs": PEAK_HBM_GBS,
@@ -492,6 +493,27 @@ def main():
     }
 
     # ---- outside the timed region -------------------------------------------------------------
+    # BASELINE configs[2] read literally is ONE 1920x1080 frame per launch; `value` is the F-frame launch (whole rounds of
+    # workgroups).  The single-frame figure goes into `config` next to it, measured in every run (also with --no-extras):
+    # median of three bursts of 10 launches, hipEvents on the launch stream.
+    if args.workload == "nlm":
+        def burst(n=10):
+            tm = Timers(mid, ctx, 1)
+            tm.tick(0, stream)
+            for _ in range(n):
+                ctx.nlm_temporal_dev(fptr[:1], optr[:1], W, H, HPARAM, SEARCH, PATCH, 0, 0, 1, mid.FMT_RGBA32F, stream)
+            tm.tock(0, stream)
+            torch.cuda.synchronize()
+            ms = tm.ms()[0] / n
+            tm.close()
+            return ms
+        burst(3)
+        s1 = sorted(burst() for _ in range(3))[1]
+        res["config"]["single_frame_launch"] = {"ms": round(s1, 4), "Mpixel/s": round(NPIX / 1e3 / s1, 1),
+                                                "frac_of_fp32_peak": round(NLM_FLOP_PER_PX * NPIX / (s1 * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                                "what": "one 1920x1080 frame per launch (configs[2] read literally): 2 full rounds of workgroups + "
+                                                        "the last round in the HALF shape; median of 3 bursts of 10 launches"}
+
     # Nothing below may cost the headline: every extra is individually guarded, and a watchdog prints the
     # line without the unfinished extras and ends every rank if they take longer than 5 minutes (a hung
     # collective would otherwise lose the whole run).
@@ -615,11 +637,8 @@ def main():
 
         guarded("streaming", extra_streaming)
 
-        def extra_single_frame():
-            s1 = sorted(time_gpu(lambda: ctx.nlm_temporal_dev(fptr[:1], optr[:1], W, H, HPARAM, SEARCH, PATCH, 0, 0, 1, 0, stream)) for _ in range(3))[1]
-            also["nlm_single_frame_latency"] = {"ms": round(s1 * 1e3, 4), "Mpixel/s": round(NPIX / 1e6 / s1, 1)}
-
-        guarded("single_frame", extra_single_frame)
+        if "single_frame_launch" in res["config"]:
+            also["nlm_single_frame_latency"] = {k_: res["config"]["single_frame_launch"][k_] for k_ in ("ms", "Mpixel/s")}
 
         def extra_temporal():
             # BASELINE configs[4]: ONE 64-frame sequence, temporal +-2 NLM, contiguous frame blocks over the ranks
@@ -735,25 +754,86 @@ def main():
 
         guarded("temporal_native", extra_temporal_native)
 
+        def pcie_ceiling(nbytes_up, nbytes_down, n=16):
+            """What the link gives in THIS run: pinned hipMemcpyAsync of n frames host->device on one stream while n frames go
+            device->host on another (the pipeline's two copy directions), nothing else on the GPU.  GB/s per direction."""
+            up, down = mid.PinnedFrames(ctx, n, nbytes_up), mid.PinnedFrames(ctx, n, nbytes_down)
+            d_up, d_down = ctx.alloc(nbytes_up), ctx.alloc(nbytes_down)
+            s_up, s_down = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+            try:
+                def go():
+                    for i in range(n):
+                        assert mid.lib.mid_memcpy_h2d(ctx.handle, d_up.ptr, up.ptrs[i], nbytes_up, s_up.cuda_stream) == 0
+                        assert mid.lib.mid_memcpy_d2h(ctx.handle, down.ptrs[i], d_down.ptr, nbytes_down, s_down.cuda_stream) == 0
+                    ctx.sync(s_up.cuda_stream)
+                    ctx.sync(s_down.cuda_stream)
+                go()
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    go()
+                    ts.append(time.perf_counter() - t0)
+                t = sorted(ts)[1]
+                return {"h2d_GBs": round(n * nbytes_up / t / 1e9, 2), "d2h_GBs": round(n * nbytes_down / t / 1e9, 2),
+                        "what": f"{n} pinned copies of {nbytes_up >> 20} MiB up and {nbytes_down >> 20} MiB down, concurrently on two streams, median of 3"}
+            finally:
+                up.free(); down.free(); d_up.free(); d_down.free()
+
+        def pipeline_passes(fr, out_u8, passes=4):
+            """The pipeline as a C caller sees it: frames already in pinned memory, a clock around the C call (and the call's own
+            timings_ms[0] beside it -- since round 4 that covers the whole call too).  First call = the context's cache empty
+            (mid_ctx_release_cached before it): ring, output slots and events are allocated inside the call.  Steady state =
+            median of `passes` further calls, which allocate nothing."""
+            h_, w_ = fr[0].shape[:2]
+            fmt = mid.FMT_RGBA8 if fr[0].dtype == np.uint8 else mid.FMT_RGBA32F
+            out_bytes = w_ * h_ * (4 if out_u8 else 16)
+            # (frames repeat in the 64-frame sequences: one pinned buffer per distinct frame)
+            uniq = {}
+            for f in fr:
+                uniq.setdefault(id(f), f)
+            pin = mid.PinnedFrames(ctx, list(uniq.values()))
+            ptr_of = dict(zip(uniq.keys(), pin.ptrs))
+            hin = [ptr_of[id(f)] for f in fr]
+            hout = mid.PinnedFrames(ctx, len(fr), out_bytes)
+            try:
+                def call():
+                    t0 = time.perf_counter()
+                    inside = ctx.sequence_nlm_pinned(hin, hout.ptrs, w_, h_, fmt, k=0, overlap=True, search=SEARCH, patch=PATCH, out_u8=out_u8)
+                    return (time.perf_counter() - t0) * 1e3, inside
+                ctx.release_cached()
+                first_ms, first_in = call()
+                rows = sorted((call() for _ in range(passes)), key=lambda r: r[0])
+                wall, (wall_in, kern, copy) = rows[len(rows) // 2]
+                mpx = lambda ms: round(len(fr) * NPIX / 1e3 / ms, 1)       # noqa: E731
+                return {"Mpixel/s_overlap": mpx(wall), "Mpixel/s_first_call": mpx(first_ms), "frames": len(fr),
+                        "call_ms": round(wall, 3), "call_ms_inside": round(wall_in, 3), "first_call_ms": round(first_ms, 3),
+                        "first_call_ms_inside": round(first_in[0], 3), "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3),
+                        f"Mpixel/s_min_max_of_{passes}_passes": [mpx(rows[-1][0]), mpx(rows[0][0])],
+                        "timing": f"clock around the C call, frames already pinned; first call with the context's cache released, then median of {passes} calls"}
+            finally:
+                pin.free(); hout.free()
+
         def extra_pipeline():
             if rank == 0 and world == 1:
                 # PCIe-inclusive: pinned host frames in, host frames out, overlapped streams (never `value`)
                 hf = [f.cpu().numpy() for f in frames[:XF]]
-                ctx.sequence_nlm(hf[:2], k=0, overlap=True, search=SEARCH, patch=PATCH)      # first-touch of pinned memory
-                _, (wall, kern, copy) = ctx.sequence_nlm(hf, k=0, overlap=True, search=SEARCH, patch=PATCH)
+                ceil32 = pcie_ceiling(NPIX * 16, NPIX * 16)
+                r = pipeline_passes(hf, out_u8=False)
                 _, (wall0, _, _) = ctx.sequence_nlm(hf, k=0, overlap=False, search=SEARCH, patch=PATCH)
-                also["pipeline_pcie_inclusive"] = {"Mpixel/s_overlap": round(len(hf) * NPIX / 1e3 / wall, 1),
-                                                   "Mpixel/s_serial": round(len(hf) * NPIX / 1e3 / wall0, 1),
-                                                   "frames": len(hf), "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3),
-                                                   "note": "host RGBA32F frames in pinned memory -> H2D, NLM (two alternating kernel streams), D2H, all overlapped; "
-                                                           "serial = a sync after every step like the reference's fence"}
+                r["Mpixel/s_serial"] = round(len(hf) * NPIX / 1e3 / wall0, 1)
+                r["pcie_ceiling"] = ceil32
+                # each direction moves 16 B per pixel; the slower direction of the concurrent-copy ceiling bounds the frame rate
+                r["pcie_frac"] = round(r["Mpixel/s_overlap"] * 16e6 / 1e9 / min(ceil32["h2d_GBs"], ceil32["d2h_GBs"]), 4)
+                r["note"] = ("host RGBA32F frames in pinned memory -> H2D, NLM (two alternating kernel streams), D2H, all overlapped; "
+                             "serial = a sync after every step like the reference's fence; pcie_frac = 16 B/px each way against the "
+                             "slower direction of the concurrent pinned-copy ceiling measured in this run")
+                also["pipeline_pcie_inclusive"] = r
                 # the reference's LDR path: RGBA8 frames in, RGBA8 frames out (u8 conversion on the device)
                 lf = [np.clip(f * 64.0, 0, 255).astype(np.uint8) for f in hf]
-                ctx.sequence_nlm(lf[:2], k=0, overlap=True, search=SEARCH, patch=PATCH, out_u8=True)
-                _, (wall8, kern8, copy8) = ctx.sequence_nlm(lf, k=0, overlap=True, search=SEARCH, patch=PATCH, out_u8=True)
-                also["pipeline_pcie_inclusive_ldr"] = {"Mpixel/s_overlap": round(len(lf) * NPIX / 1e3 / wall8, 1), "frames": len(lf),
-                                                       "kernel_ms": round(kern8, 3), "copy_ms": round(copy8, 3),
-                                                       "note": "host RGBA8 frames in, RGBA8 frames out (mid_sequence_nlm_range_u8)"}
+                r8 = pipeline_passes(lf, out_u8=True)
+                r8["note"] = "host RGBA8 frames in, RGBA8 frames out (mid_sequence_nlm_range_u8): 4 B/px each way, kernel-bound"
+                r8["pcie_frac"] = round(r8["Mpixel/s_overlap"] * 4e6 / 1e9 / min(ceil32["h2d_GBs"], ceil32["d2h_GBs"]), 4)
+                also["pipeline_pcie_inclusive_ldr"] = r8
 
         guarded("pipeline", extra_pipeline)
 
@@ -764,20 +844,12 @@ def main():
                 # exactly SEQ_FRAMES frames whatever --frames is: the first XF resident frames cycled (the keys say _64)
                 hf = [f.cpu().numpy() for f in frames[:XF]]
                 lf8 = [np.clip(f * 64.0, 0, 255).astype(np.uint8) for f in hf]
-                lf = [lf8[i % len(lf8)] for i in range(SEQ_FRAMES)]
-                def passes(fr, **kw):
-                    # pass 0 also pays for first use of the larger buffers and is dropped; of the next four the MEDIAN is
-                    # reported, with the spread beside it -- this figure moved 2480-3100 between boxes and runs in rounds
-                    # 2-3 at an unchanged kernel rate, so one pass is not a measurement
-                    rows = [ctx.sequence_nlm(fr, k=0, overlap=True, search=SEARCH, patch=PATCH, **kw)[1] for _ in range(5)][1:]
-                    rows.sort(key=lambda r: r[0])
-                    wall, kern, copy = rows[len(rows) // 2]
-                    return {"Mpixel/s_overlap": round(len(fr) * NPIX / 1e3 / wall, 1), "frames": len(fr),
-                            "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3),
-                            "Mpixel/s_min_max_of_4_passes": [round(len(fr) * NPIX / 1e3 / rows[-1][0], 1), round(len(fr) * NPIX / 1e3 / rows[0][0], 1)]}
-                also["pipeline_pcie_inclusive_ldr_64"] = passes(lf, out_u8=True)
-                hf = [hf[i % len(hf)] for i in range(SEQ_FRAMES)]
-                also["pipeline_pcie_inclusive_64"] = passes(hf)
+                also["pipeline_pcie_inclusive_ldr_64"] = pipeline_passes([lf8[i % len(lf8)] for i in range(SEQ_FRAMES)], out_u8=True)
+                r = pipeline_passes([hf[i % len(hf)] for i in range(SEQ_FRAMES)], out_u8=False)
+                c = also.get("pipeline_pcie_inclusive", {}).get("pcie_ceiling")
+                if c:
+                    r["pcie_frac"] = round(r["Mpixel/s_overlap"] * 16e6 / 1e9 / min(c["h2d_GBs"], c["d2h_GBs"]), 4)
+                also["pipeline_pcie_inclusive_64"] = r
 
         guarded("pipeline_long", extra_pipeline_long)
 

@@ -58,6 +58,7 @@ _P = ctypes.c_void_p
 _SIGNATURES = {
     "mid_ctx_create": (ctypes.c_int, [ctypes.c_int, c_void_pp]),
     "mid_ctx_destroy": (None, [_P]),
+    "mid_ctx_release_cached": (ctypes.c_int, [_P]),
     "mid_last_error": (ctypes.c_char_p, []),
     "mid_version": (ctypes.c_int, []),
     "mid_device_name": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),

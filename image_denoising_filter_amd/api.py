@@ -137,6 +137,10 @@ class Context:
         except Exception:
             pass
 
+    def release_cached(self):
+        """Free the device ring / output slots / events the frame pipeline keeps in the context between calls."""
+        _check(lib.mid_ctx_release_cached(self.handle), "mid_ctx_release_cached")
+
     @property
     def name(self):
         buf = ctypes.create_string_buffer(160)
@@ -297,6 +301,21 @@ class Context:
                                       out.ctypes.data, 1 if overlap else 0, t), "mid_nlm_multiframe")
         return out, tuple(t)
 
+    def sequence_nlm_pinned(self, hin, hout, w, h, fmt, k=2, first=0, count=None, overlap=True, hparam=0.5,
+                            search=(-7, 7), patch=(-3, 3), out_u8=False):
+        """mid_sequence_nlm_range[_u8] on host pointers the caller already holds (PinnedFrames.ptrs): nothing but the C call,
+        so a clock around it measures what a C caller sees.  Returns (wall_ms of the whole call, kernel_ms, copy_ms)."""
+        n = len(hin)
+        count = n - first if count is None else count
+        if len(hout) < count:
+            raise ValueError(f"{count} outputs asked for, {len(hout)} output buffers given")
+        prm = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], fmt)
+        t = (ctypes.c_float * 3)()
+        entry = lib.mid_sequence_nlm_range_u8 if out_u8 else lib.mid_sequence_nlm_range
+        _check(entry(self.handle, ctypes.byref(prm), (ctypes.c_void_p * n)(*hin), n, k, first, count,
+                     (ctypes.c_void_p * count)(*hout[:count]), 1 if overlap else 0, t), "mid_sequence_nlm_range")
+        return tuple(t)
+
     def sequence_nlm(self, frames, k=2, overlap=True, hparam=0.5, search=(-7, 7), patch=(-3, 3), pinned=True,
                      first=0, count=None, out_u8=False):
         """Host frames in, host frames out through the overlapped pipeline (mid_sequence_nlm_range[_u8]).
@@ -308,39 +327,50 @@ class Context:
         if not (0 <= first and count >= 1 and first + count <= n):
             raise ValueError(f"outputs [{first}, {first + count}) are not inside the {n} frames given")
         h, w = frames[0].shape[:2]
-        fmt = _fmt_of(frames[0])
-        in_bytes, out_bytes = frames[0].nbytes, w * h * (4 if out_u8 else 16)
-        hin, hout = [], []
+        out_shape, out_dtype = (h, w, 4), (np.uint8 if out_u8 else np.float32)
+        hin = PinnedFrames(self, frames) if pinned else None
+        hout = PinnedFrames(self, count, w * h * (4 if out_u8 else 16))
         try:
-            for f in frames:
-                p = ctypes.c_void_p()
-                if pinned:
-                    _check(lib.mid_alloc_host(self.handle, in_bytes, ctypes.byref(p)), "mid_alloc_host")
-                    ctypes.memmove(p.value, f.ctypes.data, in_bytes)
-                    hin.append(p.value)
-                else:
-                    hin.append(f.ctypes.data)
-            for _ in range(count):
-                q = ctypes.c_void_p()
-                _check(lib.mid_alloc_host(self.handle, out_bytes, ctypes.byref(q)), "mid_alloc_host")
-                hout.append(q.value)
-            prm = NlmParams(w, h, hparam, search[0], search[1], patch[0], patch[1], fmt)
-            t = (ctypes.c_float * 3)()
-            entry = lib.mid_sequence_nlm_range_u8 if out_u8 else lib.mid_sequence_nlm_range
-            _check(entry(self.handle, ctypes.byref(prm), (ctypes.c_void_p * n)(*hin), n, k, first, count,
-                         (ctypes.c_void_p * count)(*hout), 1 if overlap else 0, t), "mid_sequence_nlm_range")
-            outs = []
-            for q in hout:
-                o = np.empty((h, w, 4), np.uint8 if out_u8 else np.float32)
-                ctypes.memmove(o.ctypes.data, q, out_bytes)
-                outs.append(o)
-            return outs, tuple(t)
+            t = self.sequence_nlm_pinned(hin.ptrs if pinned else [f.ctypes.data for f in frames], hout.ptrs, w, h, _fmt_of(frames[0]),
+                                         k, first, count, overlap, hparam, search, patch, out_u8)
+            return [hout.array(i, out_shape, out_dtype) for i in range(count)], t
         finally:
-            if pinned:
-                for p in hin:
-                    lib.mid_free_host(self.handle, p)
-            for q in hout:
-                lib.mid_free_host(self.handle, q)
+            if hin is not None:
+                hin.free()
+            hout.free()
+
+
+class PinnedFrames:
+    """Page-locked host buffers (mid_alloc_host): the DMA source / destination of the frame pipeline, as the reference's
+    mapped staging buffer is (src/main.cpp:247-275).  PinnedFrames(ctx, frames) copies the frames in; PinnedFrames(ctx, n,
+    nbytes) allocates n empty buffers."""
+
+    def __init__(self, ctx, frames_or_n, nbytes=None):
+        self.ctx, self.ptrs = ctx, []
+        frames = None if nbytes is not None else [np.ascontiguousarray(f) for f in frames_or_n]
+        sizes = [nbytes] * int(frames_or_n) if frames is None else [f.nbytes for f in frames]
+        self.nbytes = sizes[0] if sizes else 0
+        try:
+            for i, sz in enumerate(sizes):
+                p = ctypes.c_void_p()
+                _check(lib.mid_alloc_host(ctx.handle, sz, ctypes.byref(p)), "mid_alloc_host")
+                self.ptrs.append(p.value)
+                if frames is not None:
+                    ctypes.memmove(p.value, frames[i].ctypes.data, sz)
+        except Exception:
+            self.free()
+            raise
+
+    def array(self, i, shape, dtype):
+        out = np.empty(shape, dtype)
+        ctypes.memmove(out.ctypes.data, self.ptrs[i], out.nbytes)
+        return out
+
+    def free(self):
+        for p in self.ptrs:
+            if self.ctx.handle:
+                lib.mid_free_host(self.ctx.handle, p)
+        self.ptrs = []
 
 
 # ---- an animation sharded over GPUs: the C++ RCCL path (csrc/sharded.cpp) ----------------------------------------

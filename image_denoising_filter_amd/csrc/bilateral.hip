@@ -18,13 +18,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef MID_BIL_PRIO_ACC
-#define MID_BIL_PRIO_ACC 1   /* 1: the raised priority also covers the group's accumulates */
-#endif
-#ifndef MID_BIL_GROUP
-#define MID_BIL_GROUP 2      /* tile rows per exp burst of the tiled kernel (0 = tap by tap, the round-2 loop); A/B: tools/ab_bil_libs.py */
-#endif
-
 namespace mid {
 
 struct BilArgs {
@@ -53,7 +46,7 @@ __device__ __forceinline__ unsigned xcd_remap_b(unsigned bid, unsigned nwg)
 // MODE 0: plain bilateral (range weight and colour from `in`)
 // MODE 1: layers, accumulate one layer into W      (one dispatch of bialteral_layers.comp)
 // MODE 2: layers, all layers fused + normalize     (loop src/main.cpp:1610-1623 + normalize.comp)
-template <int R, int P, int NW, int FMT, bool LINEAR, int MODE, typename BT, int SB = 8>
+template <int R, int P, int NW, int FMT, bool LINEAR, int MODE, typename BT>
 __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, const BT bt)
 {
     constexpr bool BATCH = std::is_same<BT, BilBatch>::value;
@@ -125,13 +118,13 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
 #pragma unroll
             for (int j = 0; j <= R; ++j) sij[j] = si + sj[j];
             const int base = (wv * P) * LW + lane + R + i;
-#if MID_BIL_GROUP > 0
-            // Rows in groups of MID_BIL_GROUP: exponent arguments of the group (plain VALU), then ALL its v_exp_f32 in one burst at
-            // raised issue priority, then the accumulates.  A transcendental mixed into other waves' plain instructions costs
-            // far more than its own 8 cycles (tools/microbench10/11.hip: 8 exps + 88 FMAs 357 cycles per group per SIMD against
-            // 67 + 211 alone; 274 with s_setprio around the exp burst); scheduling barriers keep the three phases apart.
+            // Rows in groups of RG = 2 (measured against 0/3/4/6/9/18: profiles/r03_ab_bilateral_exp_bursts.txt): exponent arguments
+            // of the group (plain VALU), then ALL its v_exp_f32 in one burst at raised issue priority, then the accumulates, still
+            // at raised priority.  A transcendental mixed into other waves' plain instructions costs far more than its own 8
+            // cycles (tools/microbench10/11.hip: 8 exps + 88 FMAs 357 cycles per group per SIMD against 67 + 211 alone; 274
+            // with s_setprio around the exp burst); scheduling barriers keep the three phases apart.
             // Same instructions per tap, same accumulation order: identical output bits.
-            constexpr int RG = MID_BIL_GROUP;
+            constexpr int RG = 2;
 #pragma unroll
             for (int m0 = 0; m0 < MR; m0 += RG) {
                 float4 cc[RG];
@@ -163,10 +156,6 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
                         ar[r][k] = __builtin_amdgcn_exp2f(ar[r][k]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
-#if !MID_BIL_PRIO_ACC
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
                 for (int r = 0; r < RG; ++r)
 #pragma unroll
@@ -179,37 +168,10 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
                         acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
                         accw[k] += wt;
                     }
-#if MID_BIL_PRIO_ACC
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-#endif
             }
-#else
-#pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                // keep the compiler from hoisting every row's LDS read to the top of the
-                // iteration (VGPR blow-up at large radius): rows are consumed in groups of 8
-                if (SB > 0 && m % (SB > 0 ? SB : 1) == 0 && m > 0) __builtin_amdgcn_sched_barrier(0);
-                const float4 g = gde_t[base + m * LW];
-                float4 c = g;
-                if (MODE != 0) c = img_t[base + m * LW];
-#pragma unroll
-                for (int k = 0; k < P; ++k) {
-                    const int j = m - R - k;               // row offset of this texel for output k
-                    if (j < -R || j > R) continue;
-                    const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
-                    const float arg = fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, sij[j < 0 ? -j : j])));
-                    const float wt = exp2_hw(arg);
-                    acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);
-                    acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
-                    accw[k] += wt;
-                }
-                // the guide's alpha is never used: keep it formally live so its read stays a
-                // ds_read_b128 (4 LDS cycles) instead of being narrowed to ds_read_b96 (8)
-                if (MODE != 0) asm volatile("" ::"v"(g.w), "v"(accw[P - 1]));
-            }
-#endif
         }
 #pragma unroll
         for (int k = 0; k < P; ++k) {
@@ -300,7 +262,7 @@ __global__ __launch_bounds__(512) void bilateral_rt_kernel(const BilArgs a, cons
             const int base = (wv * P) * LW + lane + R + i;
             // Tile row m feeds output k = 0 with row offset j = m - R and output k = 1 with j = m - R - 1; the first row has only the
             // k = 0 tap, the last only the k = 1 tap, and the 2R rows between them go in PAIRS with their four exps as one burst at
-            // raised issue priority, like the tuned kernel (MID_BIL_GROUP; per output the taps are still added in row order: same bits).
+            // raised issue priority, like the tuned kernel (per output the taps are still added in row order: same bits).
             auto arg_of = [&](const float4 &g, int k, int j) {
                 const float dx = cr[k] - g.x, dy = cg[k] - g.y, dz = cb[k] - g.z;
                 return fmaf(-dz, dz, fmaf(-dy, dy, fmaf(-dx, dx, fmaf(a.ks, (float)(j * j), si))));
@@ -412,12 +374,12 @@ __global__ __launch_bounds__(256) void bilateral_generic_kernel(const BilArgs a,
     }
 }
 
-template <int R, int P, int NW, int FMT, bool LINEAR, int MODE, typename BT, int SB = 8>
+template <int R, int P, int NW, int FMT, bool LINEAR, int MODE, typename BT>
 static int launch_tiled(mid_ctx *ctx, BilArgs &a, const BT &bt, int n_frames, hipStream_t s)
 {
     constexpr int LW = 64 + 2 * R, LH = NW * P + 2 * R;
     constexpr size_t lds_bytes = (size_t)LW * LH * sizeof(float4) * (MODE == 0 ? 1 : 2);
-    auto kern = bilateral_kernel<R, P, NW, FMT, LINEAR, MODE, BT, SB>;
+    auto kern = bilateral_kernel<R, P, NW, FMT, LINEAR, MODE, BT>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "bilateral tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     if (int rc = ensure_lds(ctx, (const void *)kern, lds_bytes)) return rc;
@@ -436,11 +398,7 @@ static int dispatch_radius(mid_ctx *ctx, int radius, BilArgs &a, hipStream_t s, 
     // independent waves (P = 2 rows per lane, 8 waves per workgroup) beat deeper register blocking.
     switch (radius) {
     case 4:  return launch_tiled<4, 2, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);    // BASELINE config 1 window
-#ifndef MID_BIL_R8_P
-#define MID_BIL_R8_P 2
-#define MID_BIL_R8_NW 8
-#endif
-    case 8:  return launch_tiled<8, MID_BIL_R8_P, MID_BIL_R8_NW, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);    // BASELINE configs 2 and 4 (shape: A/B builds pass -DMID_BIL_R8_P/-DMID_BIL_R8_NW)
+    case 8:  return launch_tiled<8, 2, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);    // BASELINE configs[1] and [3]
     case 10: return launch_tiled<10, 2, 16, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);  // CPU path window, src/main.cpp:1819
     case 20:                                                                 // TEXEL_WINDOW as shipped
         return launch_tiled<20, 1, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);          // 80 KB tile: two workgroups per CU (or image + guide tile)

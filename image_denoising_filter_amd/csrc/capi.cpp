@@ -72,11 +72,21 @@ extern "C" void mid_ctx_destroy(mid_ctx *ctx)
     (void)hipStreamSynchronize(ctx->compute2);
     (void)hipStreamSynchronize(ctx->upload);
     (void)hipStreamSynchronize(ctx->download);
+    pipe_cache_release(ctx);
     (void)hipStreamDestroy(ctx->compute);
     (void)hipStreamDestroy(ctx->compute2);
     (void)hipStreamDestroy(ctx->upload);
     (void)hipStreamDestroy(ctx->download);
     delete ctx;
+}
+
+extern "C" int mid_ctx_release_cached(mid_ctx *ctx)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    std::lock_guard<std::mutex> lock(ctx->pipe.mu);       // (a pipeline call in flight on another thread finishes first)
+    pipe_cache_release(ctx);
+    return MID_OK;
 }
 
 extern "C" int mid_device_name(mid_ctx *ctx, char *buf, size_t buflen)

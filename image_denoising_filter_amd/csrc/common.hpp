@@ -6,7 +6,18 @@
 #include <cstring>
 #include <mutex>
 #include <unordered_set>
+#include <vector>
 #include "../../include/mi_denoise.h"
+
+// Device buffers and events of the frame pipeline (csrc/pipeline.cpp), kept from call to call so that a steady stream of
+// sequences pays for hipMalloc / hipEventCreate once: grown on demand, released by mid_ctx_release_cached and mid_ctx_destroy.
+struct mid_pipe_set { std::vector<void *> p; size_t bytes = 0; };
+struct mid_pipe_cache {
+    std::mutex mu;                      // one pipeline call per context at a time: the calls share the context's four streams
+    mid_pipe_set ring, out;             // mid_sequence_nlm*: uploaded frames (2k + 4), output slots (4)
+    mid_pipe_set target, slots, weights, result;   // mid_nlm_multiframe
+    std::vector<hipEvent_t> ev;
+};
 
 struct mid_ctx {
     int device;
@@ -21,6 +32,7 @@ struct mid_ctx {
     // device, so it is tracked per context; contexts may be used from different threads)
     std::mutex mu;
     std::unordered_set<const void *> lds_configured;
+    mid_pipe_cache pipe;
 };
 
 namespace mid {
@@ -48,6 +60,9 @@ struct Bind {
 };
 
 inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+// Frees what the frame pipeline keeps in the context (pipeline.cpp); the context's streams must be idle.
+void pipe_cache_release(mid_ctx *ctx);
 
 // mid_nlm_temporal with the output format as an argument: out_u8 != 0 writes RGBA8 frames (pack_rgba8 of the
 // normalized pixel) instead of float4 ones -- used by the frame pipeline's u8 variant, not exported.
@@ -176,28 +191,14 @@ __device__ __forceinline__ unsigned xcd_remap_in_frame(unsigned t, unsigned tile
 // same wave costs about 7 cycles more than its own 8 (tools/microbench10/11.hip: 8 exps + 88 FMAs take 357 cycles per group per
 // SIMD issued back to back, 302 with one wait state -- or any scalar instruction -- after each exp; the parts alone sum to 278).
 // Issuing the instruction from here with its wait state attached keeps the pair together through scheduling.  Same
-// instruction, same result bits as __builtin_amdgcn_exp2f.  Used by the bilateral kernels (measured +3.5 %, 0.163 vs 0.169 ms
-// per 1080p frame at r = 8); the NLM loop keeps the builtin (there it measured -2 % / -6 %, see csrc/nlm.hip).
-#ifndef MID_EXP_NOP
-#define MID_EXP_NOP 1
-#endif
+// instruction, same result bits as __builtin_amdgcn_exp2f.  Used by the bilateral kernels' single taps (measured +3.5 % on the
+// tap-by-tap loop, profiles/r03_ab_exp_wait_state.txt); loops that issue their exps as a burst at raised priority -- the tiled
+// bilateral kernel's row groups, the NLM offset loop -- use the builtin (there the wait states measured -2 % / -6 %).
 __device__ __forceinline__ float exp2_hw(float x)
 {
-#if MID_EXP_NOP == 1
     float r;
     asm("v_exp_f32_e32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(x));
     return r;
-#elif MID_EXP_NOP == 2      /* A/B builds: the instruction from inline asm WITHOUT a wait state; with two */
-    float r;
-    asm("v_exp_f32_e32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-#elif MID_EXP_NOP == 3
-    float r;
-    asm("v_exp_f32_e32 %0, %1\n\ts_nop 1" : "=v"(r) : "v"(x));
-    return r;
-#else
-    return __builtin_amdgcn_exp2f(x);
-#endif
 }
 // Whole-wave lane shifts through DPP (no LDS traffic): value of lane l-1 / l+1; lanes without
 // a source read 0.

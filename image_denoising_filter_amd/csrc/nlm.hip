@@ -8,12 +8,12 @@
 //   * a wave owns 64 adjacent columns x R rows; lane l owns one column, keeps its target
 //     column strip T(q) in VGPRs for the whole kernel and reads Nb(q+s) from an LDS tile
 //     (float4 per texel: one conflict-free ds_read_b128 per texel);
-//   * the offsets are walked search row INNERMOST (MID_NLM_WALK): two offsets one search row apart share 13 of their
+//   * the offsets are walked search row INNERMOST (kNlmWalk, nlm_strip.hpp): two offsets one search row apart share 13 of their
 //     14 tile rows, which stay in a compile-time-indexed ring of registers -- 1.6 tile reads per offset instead of 14;
 //   * each offset runs as phases -- distances | vertical sums | DPP sums | exps | accumulate -- and the wave raises its
 //     issue priority (s_setprio) from the vertical sums on: on gfx950 a mix of one wave's plain instructions with the
 //     other wave's DPP adds / transcendentals costs far more than its parts unless the DPP/exp wave has priority
-//     (tools/microbench10-13.hip);
+//     (tools/microbench10-13.hip, microbench17.hip);
 //   * the vertical PW-tap sums are formed in registers by block prefix/suffix sums (18 adds per 8 outputs);
 //   * the horizontal PW-tap sums move across lanes with whole-wave DPP shifts fused into
 //     v_add_f32 (no LDS traffic, no shuffles): 64-(PW-1) lanes hold finished patch distances;
@@ -24,10 +24,6 @@
 //
 // Out-of-image texels are vec4(0) for both images (LDS halo zero-filled).
 #include "nlm_strip.hpp"
-
-#ifndef MID_NLM_TAIL_SPLIT
-#define MID_NLM_TAIL_SPLIT 1     /* 0: A/B builds without the HALF launch shape for the last round of small launches */
-#endif
 
 namespace mid {
 
@@ -98,84 +94,48 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
 // in a long launch the last round is noise, and the headline launch stays ONE kernel.  false = launch everything the usual way.
 static bool tail_split(const mid_ctx *ctx, const NlmArgs &a, int patch_w, bool fused, unsigned &full, unsigned &rem)
 {
-#if MID_NLM_TAIL_SPLIT
     const unsigned slots = 2u * (unsigned)ctx->cu_count;
     const unsigned nwg = nlm_tile_workgroups(a.w, a.h, patch_w, fused ? a.count : 1);
     rem = nwg % slots;
     full = nwg - rem;
     return !a.corunning && rem > 0 && rem <= (unsigned)ctx->cu_count && full / slots <= 8;
-#else
-    (void)ctx; (void)a; (void)patch_w; (void)fused; full = rem = 0;
-    return false;
-#endif
 }
 
 template <int FMT, bool FUSED>
 static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s)
 {
-    // Tile shapes were chosen by A/B on MI355X (tools/ab_nlm.py): 4 waves x R rows per
-    // workgroup (R=8: 76 KB of LDS), so two workgroups share a CU and one computes while the other
-    // refills its tile; the search-column loop is unrolled 3x (21 = 7*3) / 2x (14 = 7*2);
-    // with the van Herk vertical sums 3x measured 2 % faster than 7x (3435 vs 3362 Mpixel/s, 8 frames).
-    // The tile shape is the same for every launch size on purpose: the block-sum decomposition of
-    // vertical_box makes the rounding of a pixel depend on its row within the strip, so a fixed R keeps
-    // the output bits independent of batch size, sharding and fused-vs-dispatch-sequence (tested).  (A
-    // shorter strip, R=6, filled the CUs better for ONE 1080p frame but would have made single-frame and
-    // batched results differ in the last bit; the HALF shape of tail_split above splits strips into rows
-    // 0-3 / 4-7 with the 8-row strip's own additions instead, so it may be used wherever it is faster.)
+    // Tile shape (A/B on MI355X, LABNOTES.md): 4 waves x R = 8 rows per workgroup -- 76 KB of LDS, so two workgroups share a
+    // CU and one computes while the other refills its tile.
+    // The strip height is the same for every launch size on purpose: the block-sum decomposition of vertical_box makes the
+    // rounding of a pixel depend on its row within the strip, so a fixed R keeps the output bits independent of batch size,
+    // sharding and fused-vs-dispatch-sequence (tested).  The HALF shape of tail_split above splits strips into rows 0-3 / 4-7
+    // with the 8-row strip's own additions, so it may be used wherever it is faster.
     const bool multi = FUSED && a.k > 0;
-#ifdef MID_NLM_TUNING   // `make TUNING=1`: extra tile shapes selectable per process for tools/ab_nlm.py; not in the shipped library
-    static const int variant = getenv("MID_NLM_VARIANT") ? atoi(getenv("MID_NLM_VARIANT")) : 0;
-#endif
     if (p->search_lo == -10 && p->search_hi == 11 && p->patch_lo == -3 && p->patch_hi == 4) {   // 21x21 / 7x7 (benchmark)
-#ifdef MID_NLM_TUNING
-        if (multi && variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, FUSED, 1>(ctx, a, s);
-        if (!multi && variant == 1) return launch_strip<-10, 11, -3, 4, 8, 8, FMT, FUSED, false, 3>(ctx, a, s);
-        if (!multi && variant == 2) return launch_strip<-10, 11, -3, 4, 7, 12, FMT, FUSED, false, 3>(ctx, a, s);
-        if (!multi && variant == 5) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7>(ctx, a, s);
-        if (!multi && variant == 7) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 1, true>(ctx, a, s);   // pair-symmetry ablation
-        if (!multi && variant == 8) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3, true>(ctx, a, s);
-        if (variant == 9) {   // three workgroups per CU: 7 passes of 3 search rows (52.5 KB tile)
-            if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3, false, 3>(ctx, a, s);
-            return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3, false, 3>(ctx, a, s);
-        }
-        if (variant == 10) {  // the same passes, 7 search columns unrolled
-            if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 7, false, 3>(ctx, a, s);
-            return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 7, false, 3>(ctx, a, s);
-        }
-        // six-wave workgroups (round 3): two workgroups per CU are already 3 waves/SIMD, with 5 (SYP = 5: 84 x 58 texels,
-        // 76.1 KB) or 3 (SYP = 7: 84 x 60, 78.8 KB) tile fills per frame instead of the 7 of variants 9/10
-        if (!multi && variant == 11) return launch_strip<-10, 11, -3, 4, 8, 6, FMT, FUSED, false, 3, false, 5>(ctx, a, s);
-        if (!multi && variant == 12) return launch_strip<-10, 11, -3, 4, 8, 6, FMT, FUSED, false, 3, false, 7>(ctx, a, s);
-        if (!multi && variant == 13) return launch_strip<-10, 11, -3, 4, 8, 6, FMT, FUSED, false, 7, false, 7>(ctx, a, s);
-        if (variant == 14) {  // software-pipelined tile reads (PF)
-            if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 1, false, 0, 1>(ctx, a, s);
-            return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 1, false, 0, 1>(ctx, a, s);
-        }
-#endif
-        if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED, 3>(ctx, a, s);
+        if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED>(ctx, a, s);
         if (unsigned full, rem; tail_split(ctx, a, 7, FUSED, full, rem)) {
-            if (int rc = launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s, 0, full)) return rc;
-            return launch_strip<-10, 11, -3, 4, 4, 8, FMT, FUSED, false, 3, false, 0, 0, true>(ctx, a, s, full, rem);
+            if (int rc = launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false>(ctx, a, s, 0, full)) return rc;
+            return launch_strip<-10, 11, -3, 4, 4, 8, FMT, FUSED, false, true>(ctx, a, s, full, rem);
         }
-        return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false, 3>(ctx, a, s);
+        return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false>(ctx, a, s);
     }
     if (p->search_lo == -7 && p->search_hi == 7 && p->patch_lo == -3 && p->patch_hi == 3) {     // nonlocal.comp:5-6 as shipped
-        if (multi) return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, FUSED, 2>(ctx, a, s);
+        if (multi) return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, FUSED>(ctx, a, s);
         if (unsigned full, rem; tail_split(ctx, a, 6, FUSED, full, rem)) {
-            if (int rc = launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2>(ctx, a, s, 0, full)) return rc;
-            return launch_strip<-7, 7, -3, 3, 4, 8, FMT, FUSED, false, 2, false, 0, 0, true>(ctx, a, s, full, rem);
+            if (int rc = launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false>(ctx, a, s, 0, full)) return rc;
+            return launch_strip<-7, 7, -3, 3, 4, 8, FMT, FUSED, false, true>(ctx, a, s, full, rem);
         }
-        return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false, 2>(ctx, a, s);
+        return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false>(ctx, a, s);
     }
-    // Any other search window: the same strip kernel with the search range as a run-time argument (LDS pitch no longer a folded
-    // constant: a few % slower), instantiated in nlm_rt.hip (patches up to 9x9) and nlm_rt4.hip (10x10 .. 16x16).
-    a.slo = p->search_lo; a.shi = p->search_hi;
+    // Any other search window: the same strip kernel with the search range -- and the texel format -- as run-time arguments
+    // (LDS pitch no longer a folded constant: a few % slower), instantiated in nlm_rt.hip (patches up to 9x9) and nlm_rt4.hip
+    // (10x10 .. 16x16).
+    a.slo = p->search_lo; a.shi = p->search_hi; a.fmt = FMT;
     {
         bool handled = false;
-        int rc = nlm_dispatch_rt8(ctx, p, a, s, FMT, FUSED, &handled);
+        int rc = nlm_dispatch_rt8(ctx, p, a, s, FUSED, &handled);
         if (handled) return rc;
-        rc = nlm_dispatch_rt4(ctx, p, a, s, FMT, FUSED, &handled);
+        rc = nlm_dispatch_rt4(ctx, p, a, s, FUSED, &handled);
         if (handled) return rc;
     }
     dim3 grid(cdiv(a.w, 16), cdiv(a.h, 16), FUSED ? a.count : 1);

@@ -4,7 +4,7 @@
 
 namespace mid {
 
-template <int FMT, bool FUSED>
+template <bool FUSED>
 static int rt_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s, bool *handled)
 {
     const bool multi = FUSED && a.k > 0;
@@ -17,8 +17,8 @@ static int rt_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStrea
         auto fits4 = [&](int pw_) { return (size_t)(64 + sw - 1) * (16 + pw_ - 1 + sw - 1) * sizeof(float4) <= (size_t)ctx->lds_max; };
 #define MID_NLM_RT4(PLO_, PHI_)                                                                             \
         if (p->patch_lo == (PLO_) && p->patch_hi == (PHI_) && fits4((PHI_) - (PLO_))) {                         \
-            if (multi) return launch_strip<0, 0, PLO_, PHI_, 4, 4, FMT, FUSED, FUSED, 1>(ctx, a, s);            \
-            return launch_strip<0, 0, PLO_, PHI_, 4, 4, FMT, FUSED, false, 1>(ctx, a, s);                       \
+            if (multi) return launch_strip<0, 0, PLO_, PHI_, 4, 4, kFmtRuntime, FUSED, FUSED>(ctx, a, s);            \
+            return launch_strip<0, 0, PLO_, PHI_, 4, 4, kFmtRuntime, FUSED, false>(ctx, a, s);                       \
         }
         MID_NLM_RT4(-5, 5) MID_NLM_RT4(-5, 6) MID_NLM_RT4(-6, 6) MID_NLM_RT4(-6, 7) MID_NLM_RT4(-7, 7) MID_NLM_RT4(-7, 8) MID_NLM_RT4(-8, 8)
 #undef MID_NLM_RT4
@@ -27,10 +27,11 @@ static int rt_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStrea
     return MID_OK;
 }
 
-int nlm_dispatch_rt4(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s, int fmt, bool fused, bool *handled)
+int nlm_dispatch_rt4(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s, bool fused, bool *handled)
 {
-    if (fmt == MID_FMT_RGBA8) return fused ? rt_ranges<MID_FMT_RGBA8, true>(ctx, p, a, s, handled) : rt_ranges<MID_FMT_RGBA8, false>(ctx, p, a, s, handled);
-    return fused ? rt_ranges<MID_FMT_RGBA32F, true>(ctx, p, a, s, handled) : rt_ranges<MID_FMT_RGBA32F, false>(ctx, p, a, s, handled);
+    // (the texel format is a kernel argument here, NlmArgs::fmt: a uniform branch around the tile fill and the target fetch instead
+    // of a second set of instantiations -- half the build time and code size of these two files)
+    return fused ? rt_ranges<true>(ctx, p, a, s, handled) : rt_ranges<false>(ctx, p, a, s, handled);
 }
 
 }  // namespace mid

@@ -15,9 +15,8 @@
 // (B = 1 below; coarser batches were measured and lose overlap); the ring holds 2k+4 frames and
 // there are four output slots, so uploads run up to three frames ahead of the kernel and
 // downloads up to three behind: the stages are decoupled and the slowest one (measured: the
-// 33 MB/frame download, 0.70 ms) sets the frame rate.  This is the ONE schedule the library ships:
-// a gated chunk-launch alternative was built and measured in round 2 (no gain)
-// and removed in round 3.  Host frames
+// 33 MB/frame download, 0.70 ms) sets the frame rate.  This is the ONE schedule the library ships
+// (a gated chunk-launch alternative was measured in round 2 and removed: LABNOTES.md).  Host frames
 // allocated with mid_alloc_host (pinned) are DMA'd directly; pageable memory still works but
 // HIP stages it and the overlap is lost.
 //
@@ -34,29 +33,51 @@ using namespace mid;
 
 namespace {
 
-struct EventPool {
-    std::vector<hipEvent_t> ev;
-    ~EventPool() { for (auto e : ev) (void)hipEventDestroy(e); }
-    int make(size_t n)
-    {
-        ev.resize(n, nullptr);
-        for (auto &e : ev) MID_HIP(hipEventCreate(&e));
-        return MID_OK;
+// `n` device buffers of at least `bytes` each from the context's cache.  Every pipeline call ends with all four streams
+// synchronised, so whatever the cache holds is idle when the next call (serialised by pipe.mu) resizes it.
+int reserve(mid_pipe_set &s, size_t n, size_t bytes)
+{
+    if (bytes > s.bytes) {
+        for (void *q : s.p) (void)hipFree(q);
+        s.p.clear();
+        s.bytes = bytes;
     }
-};
+    while (s.p.size() < n) { void *q = nullptr; MID_HIP(hipMalloc(&q, s.bytes)); s.p.push_back(q); }
+    return MID_OK;
+}
 
-struct DeviceBufs {
-    std::vector<void *> p;
-    ~DeviceBufs() { for (auto q : p) (void)hipFree(q); }
-    int make(size_t n, size_t bytes)
+int reserve_events(mid_pipe_cache &c, size_t n)
+{
+    while (c.ev.size() < n) { hipEvent_t e = nullptr; MID_HIP(hipEventCreate(&e)); c.ev.push_back(e); }
+    return MID_OK;
+}
+
+// A pipeline call that returns early (an error half way) must still leave the context's streams idle: the cached buffers its
+// queued work reads and writes belong to the next call the moment this one returns.
+struct DrainOnExit {
+    mid_ctx *ctx;
+    ~DrainOnExit()
     {
-        p.assign(n, nullptr);
-        for (auto &q : p) MID_HIP(hipMalloc(&q, bytes));
-        return MID_OK;
+        (void)hipStreamSynchronize(ctx->upload);
+        (void)hipStreamSynchronize(ctx->compute);
+        (void)hipStreamSynchronize(ctx->compute2);
+        (void)hipStreamSynchronize(ctx->download);
     }
 };
 
 }  // namespace
+
+void mid::pipe_cache_release(mid_ctx *ctx)
+{
+    mid_pipe_cache &c = ctx->pipe;
+    for (mid_pipe_set *s : {&c.ring, &c.out, &c.target, &c.slots, &c.weights, &c.result}) {
+        for (void *q : s->p) (void)hipFree(q);
+        s->p.clear();
+        s->bytes = 0;
+    }
+    for (hipEvent_t e : c.ev) (void)hipEventDestroy(e);
+    c.ev.clear();
+}
 
 // Outputs [first, first+count) of an n-frame host sequence; frames outside that range are only
 // uploaded as far as the temporal window needs them (the halo of a frame block).
@@ -82,23 +103,24 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
     // Outputs could be filtered in batches of B frames per launch.  Measured on MI355X (16 x 1080p, 21x21/7x7):
     // B=1 2084 Mpixel/s, B=2 1341, B=4 1472, B=8 1403 -- coarser batches bunch the copies and lose overlap
     // while the kernel time barely changes, so one frame per launch it is (the indexing below stays general in B).
-#ifndef MID_PIPE_B
-#define MID_PIPE_B 1            /* build-time only (tools/build_alt.py pipe_b2 pipeline.cpp -DMID_PIPE_B=2): the A/B behind the figures above */
-#endif
-    const int B = MID_PIPE_B > count ? count : MID_PIPE_B;
+    constexpr int B = 1;
     const int nb = (count + B - 1) / B;
     constexpr int DEPTH = 4;                                  // batches in flight per stage
     const int ring = n_up < 2 * k + DEPTH * B ? n_up : 2 * k + DEPTH * B;
 
-    DeviceBufs dring, dout;
-    if (int rc = dring.make(ring, in_bytes)) return rc;
-    if (int rc = dout.make(DEPTH * B, dl_bytes)) return rc;
-    EventPool up0, up1, c0, c1, d0, d1;
-    for (EventPool *e : {&up0, &up1}) if (int rc = e->make(n_up)) return rc;
-    for (EventPool *e : {&c0, &c1, &d0, &d1}) if (int rc = e->make(nb)) return rc;
+    // The clock starts HERE: timings_ms[0] is what the caller waits for, set-up included.  The device ring, the output slots
+    // and the events live in the context and are only allocated when a call needs more or larger ones than any call before
+    // it (the first call of a context, a larger frame size, a wider window): in a steady stream of sequences nothing is.
+    const auto wall0 = std::chrono::steady_clock::now();
+    std::lock_guard<std::mutex> pipe_lock(ctx->pipe.mu);
+    DrainOnExit drain{ctx};
+    mid_pipe_set &dring = ctx->pipe.ring, &dout = ctx->pipe.out;
+    if (int rc = reserve(dring, ring, in_bytes)) return rc;
+    if (int rc = reserve(dout, DEPTH * B, dl_bytes)) return rc;
+    if (int rc = reserve_events(ctx->pipe, 2 * (size_t)n_up + 4 * (size_t)nb)) return rc;
+    struct Events { hipEvent_t *ev; } up0{ctx->pipe.ev.data()}, up1{up0.ev + n_up}, c0{up1.ev + n_up}, c1{c0.ev + nb}, d0{c1.ev + nb}, d1{d0.ev + nb};
     auto slot = [&](int f) { return dring.p[(f - f_lo) % ring]; };
 
-    const auto wall0 = std::chrono::steady_clock::now();
     int next_upload = f_lo;
     auto upload = [&](int f) -> int {
         if (f - f_lo >= ring) {   // the slot still holds frame f-ring, read by outputs (f-ring)-k .. (f-ring)+k
@@ -217,18 +239,19 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
     const size_t npix = (size_t)p->width * p->height;
     const size_t in_bytes = npix * (p->format == MID_FMT_RGBA8 ? 4 : 16), out_bytes = npix * 16;
 
-    DeviceBufs dtarget, dslot, dW, dout;
-    if (int rc = dtarget.make(1, in_bytes)) return rc;
-    constexpr int SLOTS = 3;                                   // neighbour frames in flight: uploads run two dispatches ahead
-    if (int rc = dslot.make(n < SLOTS ? n : SLOTS, in_bytes)) return rc;
-    if (int rc = dW.make(1, npix * sizeof(mid_weightinfo))) return rc;
-    if (int rc = dout.make(1, out_bytes)) return rc;
-    EventPool up0, up1, c0, c1, misc;
-    for (EventPool *e : {&up0, &up1, &c0, &c1})
-        if (int rc = e->make(n)) return rc;
-    if (int rc = misc.make(4)) return rc;
-
+    // (clock and cached buffers as in sequence_impl: timings_ms[0] covers the whole call)
     const auto wall0 = std::chrono::steady_clock::now();
+    std::lock_guard<std::mutex> pipe_lock(ctx->pipe.mu);
+    DrainOnExit drain{ctx};
+    mid_pipe_set &dtarget = ctx->pipe.target, &dslot = ctx->pipe.slots, &dW = ctx->pipe.weights, &dout = ctx->pipe.result;
+    if (int rc = reserve(dtarget, 1, in_bytes)) return rc;
+    constexpr int SLOTS = 3;                                   // neighbour frames in flight: uploads run two dispatches ahead
+    if (int rc = reserve(dslot, n < SLOTS ? n : SLOTS, in_bytes)) return rc;
+    if (int rc = reserve(dW, 1, npix * sizeof(mid_weightinfo))) return rc;
+    if (int rc = reserve(dout, 1, out_bytes)) return rc;
+    if (int rc = reserve_events(ctx->pipe, 4 * (size_t)n + 4)) return rc;
+    struct Events { hipEvent_t *ev; } up0{ctx->pipe.ev.data()}, up1{up0.ev + n}, c0{up1.ev + n}, c1{c0.ev + n}, misc{c1.ev + n};
+
     // target + cleared weight buffer (the reference relies on a fresh allocation being zero)
     MID_HIP(hipEventRecord(misc.ev[0], ctx->upload));
     MID_HIP(hipMemcpyAsync(dtarget.p[0], host_target, in_bytes, hipMemcpyHostToDevice, ctx->upload));

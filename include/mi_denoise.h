@@ -103,6 +103,9 @@ typedef struct mid_ctx mid_ctx;   /* opaque; bound to one HIP device */
  * (src/main.cpp:247-401): a context is one device + one compute stream. */
 int         mid_ctx_create(int device, mid_ctx **out);
 void        mid_ctx_destroy(mid_ctx *ctx);
+/* Frees the device buffers and events the frame pipeline (mid_sequence_nlm*, mid_nlm_multiframe) keeps in the context
+ * between calls -- at 1080p RGBA32F and k = 2 about 400 MB; the next pipeline call allocates again. */
+int         mid_ctx_release_cached(mid_ctx *ctx);
 const char *mid_last_error(void);
 int         mid_version(void);
 int         mid_device_name(mid_ctx *ctx, char *buf, size_t buflen);
@@ -190,7 +193,10 @@ int mid_pack_u8(mid_ctx *ctx, const float *in, size_t n_values, uint8_t *out, vo
  * consecutive frames are filtered on two alternating kernel streams (one launch's tail overlaps the next one's head).
  * host_frames/host_out are arrays of n_frames HOST pointers (RGBA32F or RGBA8 per p->format;
  * output always RGBA32F).  Synchronous: returns when every output is on the host.
- * timings_ms (optional, 3 floats): total wall, sum of kernel time, sum of copy time. */
+ * The device ring, the output slots and the events are kept in the context between calls (grown when a call needs more
+ * or larger ones; mid_ctx_release_cached / mid_ctx_destroy free them), so only a context's first call -- or the first
+ * at a larger frame size -- allocates.  Calls on one context are serialised (they share its four streams).
+ * timings_ms (optional, 3 floats): wall time of the WHOLE call, set-up included; sum of kernel time; sum of copy time. */
 int mid_sequence_nlm(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
                      int n_frames, int k, mid_pixel *const *host_out, int overlap, float *timings_ms);
 /* Same, for the output frames [first, first+count) only (host_out has `count` entries): the unit of

@@ -108,9 +108,11 @@ def test_caller_stream_orders_after_the_callers_own_work(ctx):
 
 
 def test_no_device_memory_is_leaked_by_the_entry_points(ctx):
-    """The library owns no caller-visible state beyond a context: after many pipeline / operator calls and the release of
-    the caller's buffers, free device memory is back where it started (allocator caches of torch are not involved:
-    the NumPy-level operators use mid_alloc / mid_free)."""
+    """The library owns no caller-visible state beyond a context.  The frame pipeline keeps its device ring, output slots and
+    events IN the context between calls (round 4: a steady stream of sequences allocates nothing); that cache is bounded by
+    the largest call so far, is returned by mid_ctx_release_cached, and goes with the context.  Everything else is back
+    where it started after many pipeline / operator calls and the release of the caller's buffers (allocator caches of
+    torch are not involved: the NumPy-level operators use mid_alloc / mid_free)."""
     import torch
     rng = np.random.default_rng(81)
     frames = [synth_hdr(rng, 120, 200) * 0.3 for _ in range(5)]
@@ -119,14 +121,33 @@ def test_no_device_memory_is_leaked_by_the_entry_points(ctx):
         torch.cuda.synchronize()
         return torch.cuda.mem_get_info(0)[0]
 
-    ctx.sequence_nlm(frames, k=1)                         # warm-up: code objects, streams, first allocations
-    before = free_bytes()
-    for i in range(25):
-        ctx.sequence_nlm(frames, k=i % 3, overlap=bool(i % 2), out_u8=False)
-        ctx.nlm_multiframe(frames[0], frames[:3])
-        ctx.bilateral(frames[0], 8, 2.0, 0.2)
-        ctx.bilateral_layers(frames[0], [np.zeros((120, 200, 4), np.uint8)] * 2, 4)
-        with mid.Context(0) as c2:
-            c2.nlm_temporal(frames[:2], k=1)
-    after = free_bytes()
-    assert before - after < 8 << 20, f"{(before - after) >> 20} MiB of device memory not returned"
+    def mixed_calls():
+        for i in range(25):
+            ctx.sequence_nlm(frames, k=i % 3, overlap=bool(i % 2), out_u8=False)
+            ctx.nlm_multiframe(frames[0], frames[:3])
+            ctx.bilateral(frames[0], 8, 2.0, 0.2)
+            ctx.bilateral_layers(frames[0], [np.zeros((120, 200, 4), np.uint8)] * 2, 4)
+            with mid.Context(0) as c2:
+                c2.nlm_temporal(frames[:2], k=1)
+
+    ctx.release_cached()
+    ctx.bilateral(frames[0], 8, 2.0, 0.2)                  # code objects, streams
+    empty = free_bytes()
+    mixed_calls()                                          # fills the cache to its largest shape (k = 2: 8 ring frames + 4 outputs + multiframe's 6 buffers)
+    filled = free_bytes()
+    frame_bytes = 120 * 200 * 16
+    assert 0 <= empty - filled < 24 * frame_bytes + (8 << 20), f"cache of {(empty - filled) >> 10} KiB for {frame_bytes >> 10} KiB frames"
+    mixed_calls()                                          # the same calls again allocate nothing more
+    assert abs(free_bytes() - filled) < 2 << 20
+    ctx.release_cached()
+    assert empty - free_bytes() < 8 << 20, f"{(empty - free_bytes()) >> 20} MiB of device memory not returned by mid_ctx_release_cached"
+    # a context of its own at 1080p: about 400 MB of ring + outputs while it lives, nothing afterwards
+    big = [np.zeros((1080, 1920, 4), np.float32) for _ in range(6)]
+    base = free_bytes()
+    with mid.Context(0) as c3:
+        c3.sequence_nlm(big, k=2, search=(-2, 3), patch=(-1, 2))
+        held = base - free_bytes()
+        assert held > 8 * 1080 * 1920 * 16, "the ring stays resident between calls"
+        c3.sequence_nlm(big, k=2, search=(-2, 3), patch=(-1, 2))
+        assert abs((base - free_bytes()) - held) < 8 << 20
+    assert base - free_bytes() < 8 << 20, f"{(base - free_bytes()) >> 20} MiB not returned with the context"

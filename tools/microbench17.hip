@@ -115,9 +115,10 @@ int run()
         SOLO[CA] = 1.0 / (1.0 / pa + 1.0 / pb);                                            // the SIMD's cycles per instruction, both waves' instructions counted
         printf(" | same-stream price %.2f cycles per instruction", SOLO[CA]);
     } else if (CB != IDLE && SOLO[CB] > 0 && pb > 0) {
-        // per cycle B retires 1/pb instructions costing SOLO[B] each; what is left of the cycle pays for A's 1/pa instructions
-        printf(" | price of A beside B: %.2f (same-stream %.2f); of B beside A: %.2f (same-stream %.2f)",
-               (1.0 - SOLO[CB] / pb) * pa, SOLO[CA], (1.0 - SOLO[CA] / pa) * pb, SOLO[CB]);
+        // the pair retires 1/pa + 1/pb instructions per cycle; with B's instructions charged at B's same-stream price, what is left
+        // of each cycle pays for A's: price(A beside B) = (1 - SOLO[B] / pb) * pa
+        printf(" | pair: %.2f cycles per instruction | price of A beside B: %.2f (A's same-stream price %.2f)",
+               1.0 / (1.0 / pa + 1.0 / pb), (1.0 - SOLO[CB] / pb) * pa, SOLO[CA]);
     }
     printf(" | %.0f MHz\n", clk);
     CK(hipFree(d)); CK(hipFree(c));

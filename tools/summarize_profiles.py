@@ -122,16 +122,23 @@ N_SIMD, N_CU, N_XCD = 1024, 256, 8
 # instruction classes of the inner loops, from the ISA (llvm -S census): share of the VALU
 # wave-instructions that are DPP adds and transcendentals (v_exp_f32); the rest are plain full-rate fp32/int VALU
 CLASSES = {"nlm": {"dpp": 48 / 198, "trans": 8 / 198}, "bilateral": {"dpp": 0.0, "trans": 34 / 420}}
-# issue cost per wave-instruction on one SIMD, cycles.  "floor": the hardware's best case with several waves per SIMD
-# (MI355X_MICROARCH.md: v_fma_f32 wave64 2, transcendentals 8; DPP adds are half rate: 4).  "measured": what
-# tools/microbench.hip / microbench5.hip measured at this kernel's occupancy: 2.9 / 4.85 / 8.4 at 2 waves per
-# SIMD (NLM), 2.5 / - / 8.4 at 8 waves per SIMD (bilateral).
-COST = {"floor": {"plain": 2.0, "dpp": 4.0, "trans": 8.0},
-        "nlm_measured": {"plain": 2.9, "dpp": 4.85, "trans": 8.4}, "bilateral_measured": {"plain": 2.5, "dpp": 4.4, "trans": 8.4},
-        # tools/microbench8.hip (round 3): cycles counted by the chip (s_memtime), clock measured beside them -- plain = the
-        # mix-weighted mean of two-source ops (2.25) and three-VGPR-source FMAs (2.54 at 2 waves/SIMD, 2.22 at 8)
-        "nlm_cycle_exact": {"plain": (82 * 2.25 + 60 * 2.54) / 142, "dpp": 4.39, "trans": 8.2},
-        "bilateral_cycle_exact": {"plain": 2.22, "dpp": 4.1, "trans": 8.1}}
+# Issue cost per wave-instruction on one SIMD, cycles.
+# "floor": what the hardware can do at best, from tools/microbench17.hip (two DIFFERENT streams on the two waves of a SIMD,
+# profiles/r04_microbench17_two_streams.txt): a wave64 VALU instruction occupies the SIMD-32 for 2 cycles; a DPP add costs 4 beside
+# another wave's DPP adds but only what a plain instruction costs beside another wave's plain instructions (the arrangement
+# the NLM loop's issue priorities set up), so its floor is 2 as well; v_exp_f32 holds the pipe for 8 cycles whatever runs beside it
+# (a transcendental stream starves its partner).  Round 3 priced DPP at 4 here -- a same-stream price, not a floor -- and the NLM
+# kernels read 1.03: above one.
+# "occupancy": the prices the same probe measures at the kernel's own occupancy -- NLM, 2 waves per SIMD: two-source plain 2.10,
+# three-source FMA 2.39, DPP beside plain 2.39, v_exp_f32 8.09 (one wave can only issue every 4.2-4.9 cycles, so two waves do not
+# reach 2.0); bilateral, 4-8 waves per SIMD: 2.22 / 8.1 (tools/microbench8.hip).  This is the rate a perfectly fed vector pipe
+# would reach with THIS instruction mix at THIS occupancy; the gap to 1 is what waits, tile fills, prologues and tails cost.
+COST = {"floor": {"plain": 2.0, "dpp": 2.0, "trans": 8.0},
+        "nlm_occupancy": {"plain": (82 * 2.10 + 60 * 2.39) / 142, "dpp": 2.39, "trans": 8.09},
+        "bilateral_occupancy": {"plain": 2.22, "dpp": 2.22, "trans": 8.1},
+        "same_stream": {"plain": 2.0, "dpp": 4.0, "trans": 8.0}}
+# search offsets per (pixel, neighbour frame) of the NLM kernels that have a fixed count per wave: cycles per wave-offset below
+OFFSETS = {"nlm_bench": 441, "nlm_reference_windows": 196}
 
 
 def durations_by_kernel():
@@ -154,7 +161,7 @@ def durations_by_kernel():
     return best
 
 
-def utilisation(key, cls):
+def utilisation(key, cls, offsets=None):
     d = {c: sum(v) / len(v) for c, v in pmc[key].items()}
     need = ("GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_LDS_IDX_ACTIVE")
     if any(c not in d for c in need):
@@ -170,16 +177,17 @@ def utilisation(key, cls):
         "shader_cycles_per_launch": round(cyc),
         "valu_wave_instructions_per_launch": round(d["SQ_INSTS_VALU"]),
         "valu_issue_util": round(priced(COST["floor"]) / simd_cyc, 4),
-        "valu_issue_util_def": "SQ_INSTS_VALU priced per class at the hardware's best-case issue cost (plain 2, DPP add 4, v_exp_f32 8 cycles per "
-                               "wave-instruction; class shares from the ISA census) / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs): the share of SIMD issue cycles "
-                               "the instruction mix would need on an ideally fed vector pipe",
-        "valu_issue_util_at_measured_costs": round(priced(COST[cls + "_measured"]) / simd_cyc, 4),
-        "valu_issue_util_at_measured_costs_def": "the same priced at the per-instruction issue costs the micro-benchmarks measured at this kernel's "
-                                                 "occupancy (tools/microbench*.hip, DESIGN.md 3.1): ~1.0 means the kernel sits at the issue limit of its mix",
-        "valu_issue_util_at_cycle_exact_costs": round(priced(COST[cls + "_cycle_exact"]) / simd_cyc, 4),
-        "valu_issue_util_at_cycle_exact_costs_def": "the same priced at the issue costs tools/microbench8.hip measures in shader cycles at this kernel's "
-                                                    "occupancy (s_memtime; NLM at 2 waves/SIMD: two-source plain 2.25, three-source FMA 2.54, DPP add 4.39, "
-                                                    "v_exp_f32 8.2): the fraction of a perfectly fed vector pipe the kernel reaches at its instruction mix",
+        "valu_issue_util_def": "SQ_INSTS_VALU priced per class at the hardware FLOOR (plain 2, DPP add 2 -- beside the other wave's plain "
+                               "instructions --, v_exp_f32 8 cycles per wave-instruction; class shares from the ISA census; floor measured by "
+                               "tools/microbench17.hip) / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs): the share of SIMD issue cycles the instruction mix needs "
+                               "at the very least.  A bound: it cannot exceed 1",
+        "valu_issue_util_at_occupancy": round(priced(COST[cls + "_occupancy"]) / simd_cyc, 4),
+        "valu_issue_util_at_occupancy_def": "the same priced at what tools/microbench17.hip / microbench8.hip measure at this kernel's occupancy (NLM, 2 waves "
+                                            "per SIMD: two-source plain 2.10, three-source FMA 2.39, DPP beside plain 2.39, v_exp_f32 8.09; bilateral, 4-8 "
+                                            "waves: 2.22 / 8.1): the fraction of what a perfectly fed vector pipe would do with this mix at this occupancy",
+        "valu_issue_util_at_same_stream_prices": round(priced(COST["same_stream"]) / simd_cyc, 4),
+        "valu_issue_util_at_same_stream_prices_def": "round 3's table (DPP add 4): the price of a DPP add when BOTH waves of the SIMD issue DPP adds; not a floor "
+                                                     "-- the NLM kernels exceed 1 against it because their DPP adds run beside the partner's plain instructions",
         "valu_active_share_of_wave_cycles": round(d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"], 4),
         "valu_busy_gfx94x_formula": round(d["SQ_ACTIVE_INST_VALU"] * 4 / simd_cyc, 4),
         "valu_busy_gfx94x_formula_def": "SQ_ACTIVE_INST_VALU (quad-cycles, per wave) x4 / SIMD-cycles, rocprof's derived VALUBusy for gfx94x; it sums over "
@@ -200,6 +208,16 @@ def utilisation(key, cls):
         u["valu_active_quadcycles_per_sq_busy_cycle"] = round(d["SQ_ACTIVE_INST_VALU"] / d["SQ_BUSY_CYCLES"], 3)
         u["valu_active_quadcycles_per_sq_busy_cycle_def"] = ("SQ_ACTIVE_INST_VALU [quad-cycles of wave time, summed over waves] / SQ_BUSY_CYCLES [cycles, summed "
                                                               "over 32 shader engines]; x4/32 SIMDs per engine = valu_busy_gfx94x_formula")
+    if offsets and "SQ_WAVES" in d:
+        per = simd_cyc / (d["SQ_WAVES"] * offsets)              # SIMD cycles per (wave, search offset): both waves of a SIMD counted
+        sh_ = CLASSES[cls]
+        n_inst = d["SQ_INSTS_VALU"] / (d["SQ_WAVES"] * offsets)  # VALU wave-instructions per wave-offset (198-199 in the hot loop + prologue share)
+        floor = n_inst * ((1 - sh_["dpp"] - sh_["trans"]) * 2.0 + sh_["dpp"] * 2.0 + sh_["trans"] * 8.0)
+        occ = n_inst * ((1 - sh_["dpp"] - sh_["trans"]) * COST["nlm_occupancy"]["plain"] + sh_["dpp"] * 2.39 + sh_["trans"] * 8.09)
+        u["cycles_per_wave_offset"] = {"measured": round(per, 1), "floor": round(floor, 1), "at_occupancy_prices": round(occ, 1),
+                                       "gap_to_floor": round(per - floor, 1), "gap_to_occupancy_prices": round(per - occ, 1),
+                                       "valu_instructions": round(n_inst, 1),
+                                       "def": "SIMD cycles of the launch / (SQ_WAVES x search offsets); floor and occupancy prices as in valu_issue_util*"}
     if dur:
         u["avg_launch_us_in_trace"] = round(dur[0] / 1e3, 1)
         u["effective_clock_GHz"] = round(cyc / dur[0], 3)        # cycles / ns
@@ -228,7 +246,7 @@ for name, key, cls in (("nlm_bench", pick("nlm_strip_kernel<-10, 11, -3, 4, 8, 4
                        ("bilateral_r20_texture", pick("bilateral_kernel<20, 1, 8, 0, false, 0, mid::BilOne"), "bilateral"),
                        ("bilateral_layers_r8_L4_fused", pick("bilateral_kernel<8, 2, 8, 0, false, 2, mid::BilOne"), "bilateral")):
     if key:
-        u = utilisation(key, cls)
+        u = utilisation(key, cls, OFFSETS.get(name))
         if u:
             util["kernels"][name] = u
 if util["kernels"]:

@@ -409,11 +409,23 @@ def comm_unique_id():
     return bytes(buf)
 
 
+def comm_create_all(ctxs):
+    """One process, one rank per context (mid_comm_create_all = ncclCommInitAll): the list of Comm objects, rank i on ctxs[i]."""
+    world = len(ctxs)
+    tbl = (ctypes.c_void_p * world)(*[c.handle for c in ctxs])
+    out = (ctypes.c_void_p * world)()
+    _check(lib.mid_comm_create_all(tbl, world, out), "mid_comm_create_all")
+    return [Comm(ctxs[i], None, i, world, _handle=ctypes.c_void_p(out[i])) for i in range(world)]
+
+
 class Comm:
     """One rank of an RCCL communicator bound to a Context (mid_comm_create): one process per GPU."""
 
-    def __init__(self, ctx, unique_id, rank, world):
+    def __init__(self, ctx, unique_id, rank, world, _handle=None):
         self.ctx, self.rank, self.world = ctx, rank, world
+        if _handle is not None:                      # made by comm_create_all
+            self.handle = _handle
+            return
         h = ctypes.c_void_p()
         idb = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
         _check(lib.mid_comm_create(ctx.handle, idb, rank, world, ctypes.byref(h)), "mid_comm_create")

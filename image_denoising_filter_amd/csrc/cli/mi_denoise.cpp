@@ -59,6 +59,7 @@ struct Options {
     std::string modes = "all";      // comma list of: bilateral,layers,linear,nlm,multiframe,overlap
     bool animation = false;         // new capability: temporal NLM of EVERY frame of the sequence
     int gpus = 1;                   // animation mode: frame blocks over this many devices
+    bool share_device = false;      // animation mode: every block on --device (rehearsal of --gpus N on fewer devices)
     bool halo_rccl = false;         // animation mode: blocks resident in HBM, halo frames GPU to GPU over RCCL (mid_nlm_temporal_sharded)
     long pinned_mb = 16384;         // animation mode: at most this much page-locked host memory (inputs + outputs); the rest is pageable
 };
@@ -367,7 +368,7 @@ public:
         const mid_nlm_params p{w, h, opt.nlm_h, opt.search_lo, opt.search_hi, opt.patch_lo, opt.patch_hi, fmt};
         const auto tw0 = std::chrono::steady_clock::now();
         for (int g = 0; g < G; ++g) {
-            MID_CHECK(mid_ctx_create(opt.device + g, &ctxs[g]));
+            MID_CHECK(mid_ctx_create(opt.share_device ? opt.device : opt.device + g, &ctxs[g]));
             // (a) the kernel's code object and the pipeline's streams: two tiny frames through the same entry point
             const int ww = 64, wh = 32;
             mid_nlm_params wp = p;
@@ -558,6 +559,9 @@ static void usage()
         "  --halo host|rccl          animation mode with --gpus N: 'host' (default) streams every block plus its K halo frames from host\n"
         "                            memory through the overlapped pipeline; 'rccl' keeps each block resident in its GPU's HBM and\n"
         "                            exchanges the halo frames GPU to GPU over RCCL/xGMI\n"
+        "  --share-device            animation mode: all --gpus N blocks run on --device (a rehearsal of the N-block schedule on fewer\n"
+        "                            devices; with --halo rccl it needs a stand-in for RCCL, MID_RCCL_LIBRARY: RCCL itself refuses\n"
+        "                            two ranks on one device)\n"
         "  --pinned-mb M             animation mode: page-lock at most M MiB of host memory for frames in and out (default 16384);\n"
         "                            frames beyond that, or whose page-locked allocation fails, use pageable memory\n"
         "  --cpu-radius R --cpu-sigma-s S --cpu-sigma-c C   CPU path (default 10 10.0 0.2)\n"
@@ -589,6 +593,7 @@ int main(int argc, char **argv)
         else if (a == "--temporal-k") opt.temporal_k = atoi(next());
         else if (a == "--animation") opt.animation = true;
         else if (a == "--gpus") opt.gpus = atoi(next());
+        else if (a == "--share-device") opt.share_device = true;
         else if (a == "--pinned-mb") opt.pinned_mb = atol(next());
         else if (a == "--halo") { const std::string v = next(); if (v == "rccl") opt.halo_rccl = true; else if (v != "host") { usage(); return EXIT_FAILURE; } }
         else if (a == "--cpu-radius") opt.cpu_radius = atoi(next());

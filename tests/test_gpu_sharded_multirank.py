@@ -1,0 +1,140 @@
+"""GPU suite: the C++ halo path (csrc/sharded.cpp) EXECUTED with more than one rank -- on the one-GPU box.
+
+RCCL itself refuses two ranks on one device, so until round 4 `mid_nlm_temporal_sharded` had only ever run with world = 1 (no
+sends, no receives).  Here RCCL is replaced, through MID_RCCL_LIBRARY, by tests/standin_rccl: the ten entry points sharded.cpp
+binds, for ranks that are threads of one process sharing cuda:0, every send/receive pair a device-to-device copy ordered by
+events the way a transport orders it.  With that the library's own multi-rank logic runs for real, on real kernels:
+  * mid_comm_create_all with N contexts, N threads calling mid_nlm_temporal_sharded concurrently;
+  * halo plans incl. blocks shorter than k (frames from NON-adjacent ranks), a rank that owns no frame, one frame per rank;
+  * frame_ptr's mapping of received frames to buffers, buffer reuse across calls, buffers retired when the frame size grows,
+    mid_comm_reserve, the e0/e1 hand-off between the caller's stream and the exchange stream;
+  * results bit-identical to ONE mid_nlm_temporal over the whole sequence; bytes sent / received as the plan states;
+  * mi_denoise --animation --gpus N --share-device --halo rccl: its set-up / rendezvous / collective phases, equal to --halo host;
+  * a rank whose ncclSend fails: every rank returns an error and the process exits non-zero -- no hang (mid_comm_abort).
+NOT covered: the transport -- RCCL's kernels, xGMI, multi-process rendezvous.  Those wait for a multi-GPU run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+STANDIN = os.path.join(ROOT, "tests", "standin_rccl", "libstandin_rccl.so")
+
+_WORKER = r'''
+import json, sys, threading
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import image_denoising_filter_amd as mid
+
+CFG = dict(search=(-10, 11), patch=(-3, 4))
+ref_ctx = mid.Context(0)
+rep = {"cases": []}
+
+
+def run_case(world, n, k, h, w, comms=None, ctxs=None, calls=1, reserve=False):
+    rng = np.random.default_rng(n * 100 + world * 10 + k)
+    seq = [(rng.random((h, w, 4), dtype=np.float32) * 0.8).astype(np.float32) for _ in range(n)]
+    whole = ref_ctx.nlm_temporal(seq, k=k, **CFG)
+    own = ctxs is None
+    if own:
+        ctxs = [mid.Context(0) for _ in range(world)]
+        comms = mid.comm_create_all(ctxs)
+    outs, errs, stats = {}, [], {}
+
+    def rank_main(r):
+        try:
+            c, comm = ctxs[r], comms[r]
+            start, count = mid.shard_block(n, world, r)
+            if reserve:
+                comm.reserve(h * w * 16, k)
+            d_in = [c.upload(seq[start + i]) for i in range(count)]
+            d_out = [c.alloc(h * w * 16) for _ in range(count)]
+            for _ in range(calls):
+                comm.nlm_temporal_sharded_dev([d.ptr for d in d_in], [d.ptr for d in d_out], w, h, n, k, 0.5, CFG["search"], CFG["patch"], mid.FMT_RGBA32F)
+            c.sync()
+            outs[r] = [c.download(d, (h, w, 4), np.float32) for d in d_out]
+            stats[r] = comm.last_exchange()[:2]
+        except Exception as e:  # noqa: BLE001
+            errs.append(f"rank {r}: {e}")
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a rank hangs"
+    assert not errs, errs
+    for r in range(world):
+        start, count = mid.shard_block(n, world, r)
+        assert len(outs[r]) == count
+        for i in range(count):
+            assert np.array_equal(outs[r][i], whole[start + i]), (world, n, k, r, i)
+        recv, send = mid.shard_halo_plan(n, world, k, r)
+        assert stats[r] == (len(recv) * h * w * 16, len(send) * h * w * 16), (r, stats[r])
+    rep["cases"].append([world, n, k, h, w, calls])
+    if own:
+        for cm in comms: cm.close()
+        for c in ctxs: c.close()
+
+
+# partitions of every kind: even, ragged, blocks shorter than k (frames from non-adjacent ranks), one frame per rank, a rank without a frame
+for world, n, k in ((2, 9, 1), (3, 12, 2), (4, 7, 2), (4, 5, 3), (4, 4, 2), (4, 3, 1), (2, 2, 2), (3, 3, 0)):
+    run_case(world, n, k, 70, 130)
+run_case(2, 8, 2, 1080, 1920, reserve=True)                    # BASELINE configs[4]'s frame size and k, two ranks, buffers reserved up front
+# one communicator set across several calls: buffer reuse, then a LARGER frame (old buffers retired, not freed), then smaller again
+ctxs = [mid.Context(0) for _ in range(3)]
+comms = mid.comm_create_all(ctxs)
+run_case(3, 9, 2, 40, 90, comms, ctxs, calls=2)
+run_case(3, 9, 2, 120, 200, comms, ctxs, calls=2)
+run_case(3, 7, 1, 40, 90, comms, ctxs)
+for cm in comms: cm.close()
+print("MULTIRANK " + json.dumps(rep), flush=True)
+'''
+
+
+def _env():
+    assert os.path.exists(STANDIN), "tests/standin_rccl/libstandin_rccl.so is built by `make` (or __graft_entry__.build())"
+    env = dict(os.environ, MID_RCCL_LIBRARY=STANDIN)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def test_sharded_temporal_nlm_with_two_to_four_ranks_is_bit_identical_to_one_launch(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    r = subprocess.run([sys.executable, str(script), ROOT], env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("MULTIRANK ")][0][10:])
+    assert len(rep["cases"]) == 12
+
+
+@pytest.mark.parametrize("hdr,gpus,k", [(True, 3, 2), (False, 4, 1), (True, 2, 3)])
+def test_cli_animation_on_n_ranks_sharing_the_device_equals_the_host_halo_run(tmp_path, hdr, gpus, k):
+    import image_denoising_filter_amd as mid
+    from test_cli import CLI, _make_animation
+    d, frames, _, ext = _make_animation(tmp_path, hdr, n=7)
+    outs = {}
+    for mode, extra in (("host", []), ("rccl", ["--gpus", str(gpus), "--share-device"])):
+        o = tmp_path / mode
+        o.mkdir()
+        r = subprocess.run([CLI, str(d / f"Animation01_X_0000.{ext}"), "--animation", "--temporal-k", str(k), "--outdir", str(o), "--halo", mode] + extra,
+                           cwd=tmp_path, env=_env(), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        if mode == "rccl":
+            assert f"{gpus} device(s)" in r.stdout
+        outs[mode] = [mid.load_image(o / f"output-animation-Animation01_X_{i:04d}.{ext}") for i in range(7)]
+    for a, b in zip(outs["host"], outs["rccl"]):
+        assert np.array_equal(a, b)
+
+
+def test_cli_a_rank_that_fails_inside_the_exchange_ends_the_run_with_an_error_not_a_hang(tmp_path):
+    from test_cli import CLI, _make_animation
+    d, frames, _, ext = _make_animation(tmp_path, True, n=6)
+    env = dict(_env(), STANDIN_RCCL_FAIL_SEND_RANK="1")
+    r = subprocess.run([CLI, str(d / f"Animation01_X_0000.{ext}"), "--animation", "--temporal-k", "2", "--outdir", str(tmp_path), "--halo", "rccl",
+                        "--gpus", "3", "--share-device"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0, r.stdout
+    assert "halo exchange" in r.stdout + r.stderr

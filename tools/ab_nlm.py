@@ -1,5 +1,7 @@
-"""A/B of NLM tile variants in separate processes (MID_NLM_VARIANT is read once per process).
-Needs a library built with `make clean && make TUNING=1`; the shipped build only has variant 0."""
+"""NLM timing in a fresh process per argument: 8-frame launches, single-frame launches, temporal k=2, plus a checksum line.
+Used through tools/ab_nlm_libs.py to compare library BUILDS (MID_LIB_PATH).  Until round 3 the argument selected a tile
+variant of a `make TUNING=1` build (MID_NLM_VARIANT); those variants left the product sources in round 4
+(tools/experiments/README.md) -- the argument is now only a label, the environment variable is ignored by the library."""
 import os, subprocess, sys
 code = r'''
 import sys, ctypes; sys.path.insert(0, ".")

@@ -129,12 +129,12 @@ CLASSES = {"nlm": {"dpp": 48 / 198, "trans": 8 / 198}, "bilateral": {"dpp": 0.0,
 # the NLM loop's issue priorities set up), so its floor is 2 as well; v_exp_f32 holds the pipe for 8 cycles whatever runs beside it
 # (a transcendental stream starves its partner).  Round 3 priced DPP at 4 here -- a same-stream price, not a floor -- and the NLM
 # kernels read 1.03: above one.
-# "occupancy": the prices the same probe measures at the kernel's own occupancy -- NLM, 2 waves per SIMD: two-source plain 2.10,
-# three-source FMA 2.39, DPP beside plain 2.39, v_exp_f32 8.09 (one wave can only issue every 4.2-4.9 cycles, so two waves do not
-# reach 2.0); bilateral, 4-8 waves per SIMD: 2.22 / 8.1 (tools/microbench8.hip).  This is the rate a perfectly fed vector pipe
+# "occupancy": the prices the same probe measures at the kernel's own occupancy -- NLM, 2 waves per SIMD: plain instructions in
+# 32-bit encodings (v_sub/add/mul/fmac_f32_e32: all of the loop's plain instructions) 2.10, DPP beside plain 2.39, v_exp_f32 8.09
+# (one wave can only issue every 4.2-4.9 cycles, so two waves do not reach 2.0; v_fma_f32 in its 64-bit encoding would be 2.39); bilateral, 4-8 waves per SIMD: 2.22 / 8.1 (tools/microbench8.hip).  This is the rate a perfectly fed vector pipe
 # would reach with THIS instruction mix at THIS occupancy; the gap to 1 is what waits, tile fills, prologues and tails cost.
 COST = {"floor": {"plain": 2.0, "dpp": 2.0, "trans": 8.0},
-        "nlm_occupancy": {"plain": (82 * 2.10 + 60 * 2.39) / 142, "dpp": 2.39, "trans": 8.09},
+        "nlm_occupancy": {"plain": 2.10, "dpp": 2.39, "trans": 8.09},     # (the loop's FMAs are v_fmac_f32_e32: the 32-bit-encoding class, ISA census)
         "bilateral_occupancy": {"plain": 2.22, "dpp": 2.22, "trans": 8.1},
         "same_stream": {"plain": 2.0, "dpp": 4.0, "trans": 8.0}}
 # search offsets per (pixel, neighbour frame) of the NLM kernels that have a fixed count per wave: cycles per wave-offset below
@@ -183,7 +183,7 @@ def utilisation(key, cls, offsets=None):
                                "at the very least.  A bound: it cannot exceed 1",
         "valu_issue_util_at_occupancy": round(priced(COST[cls + "_occupancy"]) / simd_cyc, 4),
         "valu_issue_util_at_occupancy_def": "the same priced at what tools/microbench17.hip / microbench8.hip measure at this kernel's occupancy (NLM, 2 waves "
-                                            "per SIMD: two-source plain 2.10, three-source FMA 2.39, DPP beside plain 2.39, v_exp_f32 8.09; bilateral, 4-8 "
+                                            "per SIMD: plain (32-bit encodings, incl. v_fmac_f32) 2.10, DPP beside plain 2.39, v_exp_f32 8.09; bilateral, 4-8 "
                                             "waves: 2.22 / 8.1): the fraction of what a perfectly fed vector pipe would do with this mix at this occupancy",
         "valu_issue_util_at_same_stream_prices": round(priced(COST["same_stream"]) / simd_cyc, 4),
         "valu_issue_util_at_same_stream_prices_def": "round 3's table (DPP add 4): the price of a DPP add when BOTH waves of the SIMD issue DPP adds; not a floor "

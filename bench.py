@@ -598,8 +598,8 @@ def main():
             nb = min(F, XF)
             s = time_gpu(lambda: ctx.bilateral_batch_dev(fptr[:nb], optr[:nb], W, H, 8, 2.0, 0.2, mid.LAYOUT_LINEAR, mid.FMT_RGBA32F, stream), 5)
             also["bilateral_r8_linear_batch"] = {"Mpixel/s": round(nb * NPIX / 1e6 / s, 1), "ms_per_frame": round(s * 1e3 / nb, 4), "frames": nb,
-                                                 "valu_frac": round(BIL_FLOP_PER_PX * F * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
-                                                 "hbm_GBs": round(BIL_BYTES_PER_PX * F * NPIX / s / 1e9, 1)}
+                                                 "valu_frac": round(BIL_FLOP_PER_PX * nb * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                                 "hbm_GBs": round(BIL_BYTES_PER_PX * nb * NPIX / s / 1e9, 1)}
 
         guarded("bilateral_batch", extra_bilateral_batch)
 

@@ -61,8 +61,12 @@ if main:   # bench.py --no-extras: only the timed loop's launches, so Calls/Aver
         # below averages the others and is the one to hold against roofline.avg_launch_ms of a bench.py run
         tr = sorted(glob.glob(os.path.join(src, "trace_main", "*", "*_kernel_trace.csv")), key=os.path.getmtime, reverse=True)
         if tr:
+            # the bench launches only: since round 4 the same run also times one-frame launches (config.single_frame_launch), which
+            # have a smaller grid -- the timed loop's launches are the ones with the LARGEST grid of the dominant kernel
+            cand = [r for r in csv.DictReader(open(tr[0])) if "nlm_strip_kernel" in r["Kernel_Name"]]
+            gmax = max(int(r["Grid_Size_X"]) for r in cand) if cand else 0
             d = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), short(r["Kernel_Name"]))
-                        for r in csv.DictReader(open(tr[0])) if "nlm_strip_kernel" in r["Kernel_Name"]))
+                        for r in cand if int(r["Grid_Size_X"]) == gmax))
             # (tools/run_profiles.sh records the pass's warm-up count: since round 3 the trace_main pass is the DEFAULT command,
             # --steps 20 --warmup 3, the one the driver times; older collections used --steps 5 --warmup 2)
             wfile = os.path.join(src, "trace_main.warmup")

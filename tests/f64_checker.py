@@ -68,3 +68,36 @@ def nlm_temporal_output(frames, t, k, hparam, search, patch, dev=None):
     if bool(zero.any()):
         out[zero] = torch.tensor([1.0, 0.0, 1.0, 1.0], dtype=torch.float64, device=out.device)
     return out.cpu().numpy()
+
+
+def bilateral_sums(img, guide, R, sigma_s, sigma_c, linear=False, dev=None):
+    """bialteral.comp:29-73 (linear=False: 2-D fetch, out-of-image texel = vec4(0)) / bialteral_linear.comp:29-72 (linear=True:
+    flat index p + dx + dy*w, outside [0, N) = vec4(0), columns wrap into the adjacent row) / bialteral_layers.comp:27-62 (guide
+    != img: range distance from the guide's rgb, colour from the image) in float64: (sum_q w c(q) [h,w,4], sum_q w [h,w]).
+    `guide` is a float array [h,w,>=3] (an RGBA8 layer is passed as its UNORM decode)."""
+    dev = device() if dev is None else dev
+    h, w = img.shape[:2]
+    n = h * w
+    P = R * w + R                                        # flat padding covers every (dx, dy) of the window in both addressings
+    def flat(a, c):
+        x = torch.as_tensor(np.ascontiguousarray(a[..., :c], dtype=np.float32), device=dev).to(torch.float64).reshape(n, c)
+        out = torch.zeros((n + 2 * P, c), dtype=torch.float64, device=dev)
+        out[P:P + n] = x
+        return out
+    ip, gp = flat(img, 4), flat(guide, 3)
+    g0 = gp[P:P + n]
+    xs = torch.arange(n, device=dev) % w
+    num = torch.zeros((n, 4), dtype=torch.float64, device=dev)
+    den = torch.zeros((n,), dtype=torch.float64, device=dev)
+    for dy in range(-R, R + 1):
+        for dx in range(-R, R + 1):
+            o = P + dx + dy * w
+            c, q = ip[o:o + n], gp[o:o + n]
+            if not linear:                               # 2-D addressing: a column outside the row is out of the image, not the next row
+                ok = ((xs + dx >= 0) & (xs + dx < w)).to(torch.float64)[:, None]
+                c, q = c * ok, q * ok
+            d2 = ((g0 - q) ** 2).sum(-1)
+            wt = torch.exp(-0.5 * (dx * dx + dy * dy) / sigma_s ** 2 - 0.5 * d2 / sigma_c ** 2)
+            num += c * wt[:, None]
+            den += wt
+    return num.reshape(h, w, 4), den.reshape(h, w)

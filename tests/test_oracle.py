@@ -118,6 +118,26 @@ def test_torch_float64_checker_agrees_with_the_oracle_and_the_numpy_restatement(
     assert rel_err(oracle.normalize(W), out) < 2e-5
 
 
+@pytest.mark.parametrize("R", [1, 4, 8])
+def test_torch_float64_bilateral_checker_agrees_with_the_oracle_and_the_numpy_restatement(R):
+    """f64_checker.bilateral_sums (flat-padded shifts, torch float64: what tests/test_gpu_bilateral_fullframe.py holds whole
+    1080p frames against) vs np_reference.py (float64) and oracle.c (fp32), both addressings and the layer-guided form."""
+    import f64_checker as f64
+    rng = np.random.default_rng(20 + R)
+    img, lay = synth_hdr(rng, 22, 29, 2.0), synth_ldr(rng, 22, 29)
+    num, den = f64.bilateral_sums(img, img, R, 2.0, 0.2)
+    n2, d2 = npr.bilateral_texture(img, R, 2.0, 0.2)
+    assert rel_err(num.cpu().numpy(), n2) < 1e-12 and rel_err(den.cpu().numpy(), d2) < 1e-12
+    assert rel_err(oracle.bilateral_texture(img, R, 2.0, 0.2), (num / den[..., None]).cpu().numpy()) < 1e-5
+    num, den = f64.bilateral_sums(img, img, R, 2.0, 0.2, linear=True)
+    lin = (num / den[..., None]).cpu().numpy()
+    assert rel_err(lin, npr.bilateral_linear(img, R, 2.0, 0.2)) < 1e-12
+    assert rel_err(oracle.bilateral_linear(img, R, 2.0, 0.2), lin) < 1e-5
+    num, den = f64.bilateral_sums(img, lay.astype(np.float32) / np.float32(255), R, 2.0, 0.2)
+    Wl = oracle.bilateral_layers_accum(img, lay, W0(22, 29), R, 2.0, 0.2)
+    assert rel_err(Wl[..., :4], num.cpu().numpy()) < 1e-5 and rel_err(Wl[..., 4], den.cpu().numpy()) < 1e-5
+
+
 # ---- properties ---------------------------------------------------------------------------------
 def test_constant_image_is_invariant_in_the_interior():
     img = np.tile(np.array([0.3, 0.6, 0.9, 1.0], np.float32), (30, 34, 1))

@@ -10,6 +10,7 @@ NumPy arrays are (h, w, 4): float32 = RGBA32F (.exr path), uint8 = RGBA8 (.png p
 WeightInfo buffers are float32 (h, w, 8): [wc.r, wc.g, wc.b, wc.a, normWeight, pad, pad, pad].
 """
 import ctypes
+import threading
 import weakref
 
 import numpy as np
@@ -117,11 +118,15 @@ class Context:
         self.handle = h
         self.device = device
         self._live = weakref.WeakSet()      # DeviceBuffers allocated through this context and not yet freed
+        self._stage_ptr, self._stage_bytes, self._stage_lock = None, 0, threading.Lock()
 
     def close(self):
         if self.handle:
             for buf in list(self._live):    # mid_free needs a live context: release what is still held, then the context
                 buf.free()
+            if self._stage_ptr:
+                lib.mid_free_host(self.handle, self._stage_ptr)
+                self._stage_ptr, self._stage_bytes = None, 0
             lib.mid_ctx_destroy(self.handle)
             self.handle = None
 
@@ -151,10 +156,38 @@ class Context:
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 
+    # Host <-> device copies of the NumPy-level operators go through ONE page-locked staging buffer per context (grown on
+    # demand) instead of handing the runtime pageable NumPy memory: for large pageable sources hipMemcpyAsync pins the caller's
+    # pages on the fly, a path on which round 4 saw the process abort once in about ten runs of the GPU suite (LABNOTES R4.8;
+    # cause not established).  The C-ABI itself accepts pageable memory as before (tests/test_gpu_pipeline.py covers it).
+    _STAGE_MIN, _STAGE_KEEP = 1 << 20, 512 << 20          # staged from 1 MiB; a staging buffer beyond 512 MiB is not kept
+
+    def _stage(self, nbytes):
+        if self._stage_bytes < nbytes:
+            if self._stage_ptr:
+                lib.mid_free_host(self.handle, self._stage_ptr)
+                self._stage_ptr, self._stage_bytes = None, 0
+            p = ctypes.c_void_p()
+            _check(lib.mid_alloc_host(self.handle, nbytes, ctypes.byref(p)), "mid_alloc_host")
+            self._stage_ptr, self._stage_bytes = p.value, nbytes
+        return self._stage_ptr
+
+    def _stage_trim(self):
+        if self._stage_bytes > self._STAGE_KEEP:
+            lib.mid_free_host(self.handle, self._stage_ptr)
+            self._stage_ptr, self._stage_bytes = None, 0
+
     def upload(self, arr, stream=None):
         arr = np.ascontiguousarray(arr)
         buf = DeviceBuffer(self, max(arr.nbytes, 16))
-        if arr.nbytes:
+        if arr.nbytes >= self._STAGE_MIN:
+            with self._stage_lock:
+                src = self._stage(arr.nbytes)
+                ctypes.memmove(src, arr.ctypes.data, arr.nbytes)
+                _check(lib.mid_memcpy_h2d(self.handle, buf.ptr, src, arr.nbytes, stream), "mid_memcpy_h2d")
+                self.sync(stream)
+                self._stage_trim()
+        elif arr.nbytes:
             _check(lib.mid_memcpy_h2d(self.handle, buf.ptr, arr.ctypes.data, arr.nbytes, stream), "mid_memcpy_h2d")
             self.sync(stream)
         return buf
@@ -162,7 +195,14 @@ class Context:
     def download(self, buf, shape, dtype, stream=None):
         out = np.empty(shape, dtype=dtype)
         ptr = buf.ptr if isinstance(buf, DeviceBuffer) else int(buf)
-        if out.nbytes:
+        if out.nbytes >= self._STAGE_MIN:
+            with self._stage_lock:
+                dst = self._stage(out.nbytes)
+                _check(lib.mid_memcpy_d2h(self.handle, dst, ptr, out.nbytes, stream), "mid_memcpy_d2h")
+                self.sync(stream)
+                ctypes.memmove(out.ctypes.data, dst, out.nbytes)
+                self._stage_trim()
+        elif out.nbytes:
             _check(lib.mid_memcpy_d2h(self.handle, out.ctypes.data, ptr, out.nbytes, stream), "mid_memcpy_d2h")
             self.sync(stream)
         return out

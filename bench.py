@@ -532,7 +532,7 @@ def main():
     in_flight = {"extra": None}
 
     def on_timeout():
-        also["error"] = (f"extras did not finish within 300 s (in flight: {in_flight['extra']}); line emitted by the watchdog, "
+        also["error"] = (f"extras did not finish within {watchdog_s:g} s (in flight: {in_flight['extra']}); line emitted by the watchdog, "
                          "which then ends the process with exit code 3")
         emit()
         # A process that has touched the GPU and is abandoned in the middle of an extra -- possibly inside a collective
@@ -540,13 +540,16 @@ def main():
         # complete (the timed region and its max-over-ranks reduction finished on every rank before any extra started),
         # `also.error` names the extra that was in flight, and the exit code says that this run did not end cleanly.
         os._exit(3)
-    watchdog = threading.Timer(300.0, on_timeout)
+    watchdog_s = float(os.environ.get("MID_BENCH_WATCHDOG_S", "300"))      # (tests shorten it; see MID_BENCH_TEST_HANG below)
+    watchdog = threading.Timer(watchdog_s, on_timeout)
     watchdog.daemon = True
     watchdog.start()
 
     def guarded(name, fn):
         in_flight["extra"] = name
         try:
+            if os.environ.get("MID_BENCH_TEST_HANG") == name:       # tests/test_gpu_rccl_one_rank.py: an extra that never returns
+                time.sleep(3600)
             fn()
         except Exception as e:          # an extra must never take the measurement down with it
             also[name + "_error"] = f"{type(e).__name__}: {e}"

@@ -141,3 +141,19 @@ def test_bench_stdout_is_exactly_one_json_line_with_the_native_rccl_extra(tmp_pa
     assert nat["bit_identical_to_single_launch_per_rank"] == [True] and nat["halo_bytes_recv_per_rank"] == [0]
     assert not [k for k in d["also"] if k.endswith("_error")], d["also"]
     assert d["also"]["bilateral_r8_texture_over_linear"] > 0
+
+
+def test_bench_watchdog_prints_the_headline_names_the_hung_extra_and_exits_nonzero(tmp_path):
+    """An extra that never returns (here simulated; on N > 1 it would be a collective whose peer is gone): the watchdog
+    prints the complete headline line with `also.error` naming the extra in flight and ends the process with exit code 3 --
+    for every world size (a process abandoned in the middle of GPU work must not report success)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MID_BENCH_WATCHDOG_S="25", MID_BENCH_TEST_HANG="bilateral_batch")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and "bilateral_batch" in d["also"]["error"] and "exit code 3" in d["also"]["error"]
+    assert "bilateral_r8_linear" in d["also"], "extras that finished before the hang are in the line"

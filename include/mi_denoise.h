@@ -248,8 +248,9 @@ int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const void *host_t
  *   on.  A call on a different stream than the previous one returns MID_ERR_INVALID unless the previous call's work has
  *   finished (e.g. after mid_stream_sync on the earlier stream).
  *   Results are the bits of one mid_nlm_temporal over the whole sequence by construction (same kernels, same tile
- *   shape, same frame tables: tests/test_shard_native_plan.py); executed on hardware for world = 1 only so far -- an
- *   N >= 2 run is gated by bench.py's `bit_identical_to_single_launch_per_rank`.
+ *   shape, same frame tables: tests/test_shard_native_plan.py).  Executed so far: with RCCL itself for world = 1; with 2-4
+ *   ranks sharing one device against a test-only stand-in for the transport (tests/standin_rccl), bit-identical in 12
+ *   partitions.  RCCL between two devices has not run yet: bench.py gates it with `bit_identical_to_single_launch_per_rank`.
  * mid_comm_reserve: allocates the 2k receive buffers for frames of up to max_frame_bytes up front, so that no sharded
  *   call allocates (optional; otherwise they are allocated on first use and retired, not freed, when the frame size grows).
  * mid_comm_abort: ncclCommAbort -- tears the rank's connections down without waiting for outstanding operations; the

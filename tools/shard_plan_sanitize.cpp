@@ -1,0 +1,45 @@
+// shard_plan_sanitize.cpp -- ASan/UBSan sweep of the pure-host sharding entry points of csrc/sharded.cpp (mid_shard_block /
+// mid_shard_halo_plan / mid_shard_launch_plan): every (n <= 70, world <= 9, k <= 6, rank), caller arrays of capacity 0, 1, 3 and
+// 64 (too-small capacities must come back as error codes, never as writes past the arrays), bad arguments.  CPU build only; the
+// kernel entry points the host files reference are stubbed (never reached).  Built and run by tests/test_shard_native_plan.py:
+//   hipcc -x hip --offload-arch=gfx950 -fno-gpu-sanitize -fsanitize=address,undefined -O1 -g -std=c++17 -Iinclude \
+//         csrc/sharded.cpp csrc/capi.cpp csrc/pipeline.cpp tools/shard_plan_sanitize.cpp -o shard_plan_sanitize -ldl
+#include <cstdio>
+#include <vector>
+#include "../include/mi_denoise.h"
+#include "../image_denoising_filter_amd/csrc/common.hpp"
+
+extern "C" int mid_nlm_temporal(mid_ctx *, const mid_nlm_params *, const void *const *, int, int, int, int, mid_pixel *const *, void *) { return MID_ERR_UNSUPPORTED; }
+extern "C" int mid_nlm_accum(mid_ctx *, const mid_nlm_params *, const void *, const void *, mid_weightinfo *, void *) { return MID_ERR_UNSUPPORTED; }
+extern "C" int mid_normalize(mid_ctx *, const mid_normalize_params *, const mid_weightinfo *, mid_pixel *, void *) { return MID_ERR_UNSUPPORTED; }
+int mid::nlm_temporal_out(mid_ctx *, const mid_nlm_params *, const void *const *, int, int, int, int, void *const *, int, void *, int) { return MID_ERR_UNSUPPORTED; }
+
+int main()
+{
+    long calls = 0, refused = 0, bad = 0;
+    for (int n = 0; n <= 70; ++n)
+        for (int world = 1; world <= 9; ++world)
+            for (int k = 0; k <= 6; ++k)
+                for (int rank = 0; rank < world; ++rank) {
+                    int s = -1, c = -1;
+                    if (mid_shard_block(n, world, rank, &s, &c) || s < 0 || c < 0 || s + c > n) { ++bad; continue; }
+                    for (int cap : {0, 1, 3, 64}) {
+                        // exactly `cap` entries: a write past them is a heap overflow ASan reports
+                        std::vector<int> rp(cap), rf(cap), sp(cap), sf(cap), rows(6 * (size_t)cap);
+                        int nr = -1, ns = -1, nrow = -1;
+                        int rc = mid_shard_halo_plan(n, world, k, rank, cap, rp.data(), rf.data(), &nr, sp.data(), sf.data(), &ns);
+                        if (rc) ++refused; else if (nr > cap || ns > cap || nr < 0 || ns < 0) ++bad;
+                        rc = mid_shard_launch_plan(n, world, k, rank, cap, rows.data(), &nrow);
+                        if (rc) ++refused; else if (nrow > cap || nrow < 0) ++bad;
+                        calls += 2;
+                    }
+                }
+    int a = 0;
+    bad += mid_shard_block(4, 0, 0, &a, &a) == 0;
+    bad += mid_shard_block(-1, 2, 0, &a, &a) == 0;
+    bad += mid_shard_block(4, 2, 2, &a, &a) == 0;
+    bad += mid_shard_halo_plan(4, 2, -1, 0, 4, nullptr, nullptr, &a, nullptr, nullptr, &a) == 0;
+    bad += mid_shard_launch_plan(4, 2, 1, 0, 8, nullptr, &a) == 0;
+    printf("shard_plan_sanitize: %ld calls, %ld refused for capacity, %ld wrong\n", calls, refused, bad);
+    return bad ? 1 : 0;
+}

@@ -96,7 +96,8 @@ print("MULTIRANK " + json.dumps(rep), flush=True)
 
 
 def _env():
-    assert os.path.exists(STANDIN), "tests/standin_rccl/libstandin_rccl.so is built by `make` (or __graft_entry__.build())"
+    if not os.path.exists(STANDIN):          # normally built by `make` / __graft_entry__.build() and shipped with the tree
+        subprocess.run(["make", "-C", os.path.dirname(STANDIN)], check=True, capture_output=True, timeout=600)
     env = dict(os.environ, MID_RCCL_LIBRARY=STANDIN)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return env

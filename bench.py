@@ -573,7 +573,7 @@ def main():
         def extra_bilateral():
             # The two layouts run the same inner loop (identical opcode stream; only the tile fill differs).  Timed one after
             # the other, 10 launches each, whichever came SECOND read 3-6 % slower (rounds 1-2: 0.181 vs 0.193 ms; the
-            # profiler's launch mix, which runs texture first, and an interleaved A/B both show them equal):
+            # profiler's launch mix, which runs texture first, and an interleaved A/B both show them equal, LABNOTES.md rounds 1-3 section 3.2):
             # 2 ms of 0.18 ms launches between host-side gaps sit on the GPU's clock ramp.  So: warm both, then alternate
             # them (order flipped every repetition), 20 launches per timing, and report each layout's median.
             layouts = (("bilateral_r8_linear", mid.LAYOUT_LINEAR), ("bilateral_r8_texture", mid.LAYOUT_TEXTURE))

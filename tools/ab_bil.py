@@ -1,5 +1,5 @@
 """Times the bilateral kernels at r=4/8/10/20.  It was the A/B driver for tile shapes (MID_BIL_VARIANT selected
-template instantiations that were removed once the winners were fixed in dispatch_radius);
+template instantiations that were removed once the winners were fixed in dispatch_radius, see LABNOTES.md, rounds 1-3 section 3.2);
 to A/B a new shape, build a second library and point MID_LIB_PATH at it."""
 import os, subprocess, sys
 code = r'''

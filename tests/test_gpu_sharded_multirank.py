@@ -62,7 +62,7 @@ def run_case(world, n, k, h, w, comms=None, ctxs=None, calls=1, reserve=False):
         except Exception as e:  # noqa: BLE001
             errs.append(f"rank {r}: {e}")
 
-    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]      # (daemon: a rank stuck in the exchange must not keep the process alive)
     for t in th: t.start()
     for t in th: t.join(timeout=120)
     assert not any(t.is_alive() for t in th), "a rank hangs"

@@ -10,7 +10,6 @@ NumPy arrays are (h, w, 4): float32 = RGBA32F (.exr path), uint8 = RGBA8 (.png p
 WeightInfo buffers are float32 (h, w, 8): [wc.r, wc.g, wc.b, wc.a, normWeight, pad, pad, pad].
 """
 import ctypes
-import threading
 import weakref
 
 import numpy as np
@@ -118,15 +117,11 @@ class Context:
         self.handle = h
         self.device = device
         self._live = weakref.WeakSet()      # DeviceBuffers allocated through this context and not yet freed
-        self._stage_ptr, self._stage_bytes, self._stage_lock = None, 0, threading.Lock()
 
     def close(self):
         if self.handle:
             for buf in list(self._live):    # mid_free needs a live context: release what is still held, then the context
                 buf.free()
-            if self._stage_ptr:
-                lib.mid_free_host(self.handle, self._stage_ptr)
-                self._stage_ptr, self._stage_bytes = None, 0
             lib.mid_ctx_destroy(self.handle)
             self.handle = None
 
@@ -156,38 +151,13 @@ class Context:
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 
-    # Host <-> device copies of the NumPy-level operators go through ONE page-locked staging buffer per context (grown on
-    # demand) instead of handing the runtime pageable NumPy memory: for large pageable sources hipMemcpyAsync pins the caller's
-    # pages on the fly, a path on which round 4 saw the process abort once in about ten runs of the GPU suite (LABNOTES R4.8;
-    # cause not established).  The C-ABI itself accepts pageable memory as before (tests/test_gpu_pipeline.py covers it).
-    _STAGE_MIN, _STAGE_KEEP = 1 << 20, 512 << 20          # staged from 1 MiB; a staging buffer beyond 512 MiB is not kept
-
-    def _stage(self, nbytes):
-        if self._stage_bytes < nbytes:
-            if self._stage_ptr:
-                lib.mid_free_host(self.handle, self._stage_ptr)
-                self._stage_ptr, self._stage_bytes = None, 0
-            p = ctypes.c_void_p()
-            _check(lib.mid_alloc_host(self.handle, nbytes, ctypes.byref(p)), "mid_alloc_host")
-            self._stage_ptr, self._stage_bytes = p.value, nbytes
-        return self._stage_ptr
-
-    def _stage_trim(self):
-        if self._stage_bytes > self._STAGE_KEEP:
-            lib.mid_free_host(self.handle, self._stage_ptr)
-            self._stage_ptr, self._stage_bytes = None, 0
-
+    # NumPy arrays are pageable memory.  The C-ABI itself keeps such memory away from the HIP runtime's pin-on-the-fly path
+    # (mid_memcpy_h2d / mid_memcpy_d2h move it through the context's page-locked bounce buffers, csrc/hostcopy.cpp), so
+    # these two are plain calls: what the tests exercise here is what any caller of the library gets.
     def upload(self, arr, stream=None):
         arr = np.ascontiguousarray(arr)
         buf = DeviceBuffer(self, max(arr.nbytes, 16))
-        if arr.nbytes >= self._STAGE_MIN:
-            with self._stage_lock:
-                src = self._stage(arr.nbytes)
-                ctypes.memmove(src, arr.ctypes.data, arr.nbytes)
-                _check(lib.mid_memcpy_h2d(self.handle, buf.ptr, src, arr.nbytes, stream), "mid_memcpy_h2d")
-                self.sync(stream)
-                self._stage_trim()
-        elif arr.nbytes:
+        if arr.nbytes:
             _check(lib.mid_memcpy_h2d(self.handle, buf.ptr, arr.ctypes.data, arr.nbytes, stream), "mid_memcpy_h2d")
             self.sync(stream)
         return buf
@@ -195,14 +165,7 @@ class Context:
     def download(self, buf, shape, dtype, stream=None):
         out = np.empty(shape, dtype=dtype)
         ptr = buf.ptr if isinstance(buf, DeviceBuffer) else int(buf)
-        if out.nbytes >= self._STAGE_MIN:
-            with self._stage_lock:
-                dst = self._stage(out.nbytes)
-                _check(lib.mid_memcpy_d2h(self.handle, dst, ptr, out.nbytes, stream), "mid_memcpy_d2h")
-                self.sync(stream)
-                ctypes.memmove(out.ctypes.data, dst, out.nbytes)
-                self._stage_trim()
-        elif out.nbytes:
+        if out.nbytes:
             _check(lib.mid_memcpy_d2h(self.handle, out.ctypes.data, ptr, out.nbytes, stream), "mid_memcpy_d2h")
             self.sync(stream)
         return out
@@ -357,9 +320,11 @@ class Context:
         return tuple(t)
 
     def sequence_nlm(self, frames, k=2, overlap=True, hparam=0.5, search=(-7, 7), patch=(-3, 3), pinned=True,
-                     first=0, count=None, out_u8=False):
+                     first=0, count=None, out_u8=False, pinned_out=True):
         """Host frames in, host frames out through the overlapped pipeline (mid_sequence_nlm_range[_u8]).
         out_u8: outputs converted to RGBA8 on the device like the reference's read-back (src/main.cpp:97-103).
+        pinned / pinned_out = False: the NumPy arrays themselves (pageable memory) are the sources / destinations, which
+        the library moves through its bounce buffers (csrc/hostcopy.cpp).
         Returns (outputs for frames first..first+count-1, (wall_ms, kernel_ms, copy_ms))."""
         frames = _same_frames(frames, "sequence_nlm")
         n = len(frames)
@@ -369,15 +334,18 @@ class Context:
         h, w = frames[0].shape[:2]
         out_shape, out_dtype = (h, w, 4), (np.uint8 if out_u8 else np.float32)
         hin = PinnedFrames(self, frames) if pinned else None
-        hout = PinnedFrames(self, count, w * h * (4 if out_u8 else 16))
+        hout = PinnedFrames(self, count, w * h * (4 if out_u8 else 16)) if pinned_out else None
+        outs = None if pinned_out else [np.empty(out_shape, out_dtype) for _ in range(count)]
         try:
-            t = self.sequence_nlm_pinned(hin.ptrs if pinned else [f.ctypes.data for f in frames], hout.ptrs, w, h, _fmt_of(frames[0]),
+            t = self.sequence_nlm_pinned(hin.ptrs if pinned else [f.ctypes.data for f in frames],
+                                         hout.ptrs if pinned_out else [o.ctypes.data for o in outs], w, h, _fmt_of(frames[0]),
                                          k, first, count, overlap, hparam, search, patch, out_u8)
-            return [hout.array(i, out_shape, out_dtype) for i in range(count)], t
+            return (outs if outs is not None else [hout.array(i, out_shape, out_dtype) for i in range(count)]), t
         finally:
             if hin is not None:
                 hin.free()
-            hout.free()
+            if hout is not None:
+                hout.free()
 
 
 class PinnedFrames:

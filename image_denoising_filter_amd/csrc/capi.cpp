@@ -73,6 +73,7 @@ extern "C" void mid_ctx_destroy(mid_ctx *ctx)
     (void)hipStreamSynchronize(ctx->upload);
     (void)hipStreamSynchronize(ctx->download);
     pipe_cache_release(ctx);
+    bounce_release(ctx);
     (void)hipStreamDestroy(ctx->compute);
     (void)hipStreamDestroy(ctx->compute2);
     (void)hipStreamDestroy(ctx->upload);
@@ -86,6 +87,7 @@ extern "C" int mid_ctx_release_cached(mid_ctx *ctx)
     if (b.rc) return b.rc;
     std::lock_guard<std::mutex> lock(ctx->pipe.mu);       // (a pipeline call in flight on another thread finishes first)
     pipe_cache_release(ctx);
+    bounce_release(ctx);                                   // the two page-locked bounce sets of csrc/hostcopy.cpp (32 MiB)
     return MID_OK;
 }
 
@@ -153,8 +155,7 @@ extern "C" int mid_memcpy_h2d(mid_ctx *ctx, void *dst, const void *src, size_t b
     Bind b(ctx, stream);
     if (b.rc) return b.rc;
     MID_REQUIRE(dst && src, "memcpy_h2d: NULL pointer");
-    MID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b.s));
-    return MID_OK;
+    return copy_h2d(ctx, dst, src, bytes, b.s);      // pinned: one async DMA; pageable: through the context's bounce buffers
 }
 
 extern "C" int mid_memcpy_d2h(mid_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream)
@@ -162,8 +163,7 @@ extern "C" int mid_memcpy_d2h(mid_ctx *ctx, void *dst, const void *src, size_t b
     Bind b(ctx, stream);
     if (b.rc) return b.rc;
     MID_REQUIRE(dst && src, "memcpy_d2h: NULL pointer");
-    MID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b.s));
-    return MID_OK;
+    return copy_d2h(ctx, dst, src, bytes, b.s);
 }
 
 extern "C" int mid_memset(mid_ctx *ctx, void *dst, int value, size_t bytes, void *stream)

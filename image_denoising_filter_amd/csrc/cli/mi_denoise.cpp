@@ -61,6 +61,7 @@ struct Options {
     int gpus = 1;                   // animation mode: frame blocks over this many devices
     bool share_device = false;      // animation mode: every block on --device (rehearsal of --gpus N on fewer devices)
     bool halo_rccl = false;         // animation mode: blocks resident in HBM, halo frames GPU to GPU over RCCL (mid_nlm_temporal_sharded)
+    bool pageable_host = false;     // reference modes: keep decoded images and results in ordinary memory (the C-ABI bounces them)
     long pinned_mb = 16384;         // animation mode: at most this much page-locked host memory (inputs + outputs); the rest is pageable
 };
 
@@ -109,25 +110,36 @@ class DenoiseApplication {
 
     static bool is_hdr(const std::string &p) { return fs::path(p).extension() == ".exr"; }   // src/main.cpp:1380
 
+    // A decoded image.  With a context it lives in page-locked memory (mid_image_load_pinned), the HIP counterpart of the
+    // host-visible staging buffer the reference memcpy's its decoded pixels into (LoadImageDataToBuffer,
+    // src/main.cpp:1105-1142), so every copy the GPU modes issue is a plain asynchronous DMA.  Without one (RunOnCPU), or
+    // when page-locked memory runs out, it is ordinary memory, which the C-ABI moves through its own pinned bounce buffers.
     struct HostImage {
         int w = 0, h = 0, format = 0;
-        std::vector<uint8_t> bytes;
+        mid_ctx *pin_ctx = nullptr;          // non-NULL: `img.data` is pinned and freed through this context
+        mid_image img{};
+        HostImage() = default;
+        HostImage(const HostImage &) = delete;
+        HostImage &operator=(const HostImage &) = delete;
+        HostImage(HostImage &&o) noexcept : w(o.w), h(o.h), format(o.format), pin_ctx(o.pin_ctx), img(o.img) { o.img.data = nullptr; }
+        ~HostImage()
+        {
+            if (!img.data) return;
+            if (pin_ctx) (void)mid_image_free_pinned(pin_ctx, &img); else mid_image_free(&img);
+        }
+        size_t size() const { return (size_t)w * h * (format == MID_FMT_RGBA32F ? 16 : 4); }
+        const uint8_t *data() const { return (const uint8_t *)img.data; }
     };
 
-    static HostImage load(const std::string &path, bool force_png)
+    static HostImage load(const std::string &path, bool force_png, mid_ctx *ctx = nullptr)
     {
         // layers are always decoded as PNG (src/main.cpp:1396 passes a_isHDR=false)
         if (force_png && is_hdr(path)) throw std::runtime_error("layer " + path + " is not a PNG");
-        mid_image img{};
-        if (int rc = mid_image_load(path.c_str(), &img)) {
-            (void)rc;
-            throw std::runtime_error(mid_last_error());        // lodepng error -> runtime_error, src/main.cpp:202
-        }
         HostImage h;
-        h.w = img.width; h.h = img.height; h.format = img.format;
-        const size_t n = (size_t)img.width * img.height * (img.format == MID_FMT_RGBA32F ? 16 : 4);
-        h.bytes.assign((uint8_t *)img.data, (uint8_t *)img.data + n);
-        mid_image_free(&img);
+        if (ctx && mid_image_load_pinned(ctx, path.c_str(), &h.img) == MID_OK) h.pin_ctx = ctx;
+        else if (mid_image_load(path.c_str(), &h.img))
+            throw std::runtime_error(mid_last_error());        // lodepng error -> runtime_error, src/main.cpp:202
+        h.w = h.img.width; h.h = h.img.height; h.format = h.img.format;
         return h;
     }
 
@@ -182,7 +194,9 @@ public:
         std::vector<std::string> frameNames, layerNames;
         discover(frameNames, layerNames, multiframe, useLayers);
         const bool hdr = is_hdr(opt.image);
-        HostImage target = load(opt.image, false);
+        mid_ctx *pin = opt.pageable_host ? nullptr : ctx;              // where decoded images live
+        if (opt.pageable_host) std::cout << "\thost buffers: pageable (bounced inside the library)\n";
+        HostImage target = load(opt.image, false, pin);
         const int w = target.w, h = target.h;
         const size_t npix = (size_t)w * h, out_bytes = npix * sizeof(Pixel);
         const int fmt = target.format;
@@ -190,7 +204,17 @@ public:
             if (im.w != w || im.h != h || im.format != fmt) throw std::runtime_error(name + ": size/format differs from the target image");
         };
 
-        std::vector<Pixel> result(npix);
+        // the read-back target: page-locked like the reference's staging buffer (GetImageFromGPU maps it, src/main.cpp:91-96);
+        // ordinary memory if that allocation fails
+        struct Result {
+            mid_ctx *c; void *pinned = nullptr; std::vector<Pixel> fallback;
+            Result(mid_ctx *ctx, size_t n, bool want_pinned) : c(ctx)
+            {
+                if (!want_pinned || mid_alloc_host(c, n * sizeof(Pixel), &pinned)) { pinned = nullptr; fallback.resize(n); }
+            }
+            ~Result() { if (pinned) (void)mid_free_host(c, pinned); }
+            Pixel *data() { return pinned ? (Pixel *)pinned : fallback.data(); }
+        } result(ctx, npix, !opt.pageable_host);
         mid_timer *tm = nullptr;
         MID_CHECK(mid_timer_create(ctx, &tm));
         struct TimerGuard { mid_timer *t; ~TimerGuard() { mid_timer_destroy(t); } } tguard{tm};
@@ -221,19 +245,19 @@ public:
                 if (execAndCopyOverlap && list.size() > 9) list.resize(9);
             }
             std::vector<HostImage> frames;
-            for (auto &f : list) { frames.push_back(load(f, false)); check_dims(frames.back(), f); }
+            for (auto &f : list) { frames.push_back(load(f, false, pin)); check_dims(frames.back(), f); }
             std::vector<const void *> ptrs;
-            for (auto &f : frames) ptrs.push_back(f.bytes.data());
+            for (auto &f : frames) ptrs.push_back(f.data());
             mid_nlm_params p{w, h, opt.nlm_h, opt.search_lo, opt.search_hi, opt.patch_lo, opt.patch_hi, fmt};
             float t[3] = {0, 0, 0};
-            MID_CHECK(mid_nlm_multiframe(ctx, &p, target.bytes.data(), ptrs.data(), (int)ptrs.size(), (mid_pixel *)result.data(),
+            MID_CHECK(mid_nlm_multiframe(ctx, &p, target.data(), ptrs.data(), (int)ptrs.size(), (mid_pixel *)result.data(),
                                          execAndCopyOverlap ? 1 : 0, t));
             m_execMs = t[1]; m_transferMs = t[2];
         } else {
             void *dIn = nullptr, *dOut = nullptr;
-            MID_CHECK(mid_alloc(ctx, target.bytes.size(), &dIn));
+            MID_CHECK(mid_alloc(ctx, target.size(), &dIn));
             MID_CHECK(mid_alloc(ctx, out_bytes, &dOut));
-            timed(m_transferMs, [&] { MID_CHECK(mid_memcpy_h2d(ctx, dIn, target.bytes.data(), target.bytes.size(), nullptr)); });
+            timed(m_transferMs, [&] { MID_CHECK(mid_memcpy_h2d(ctx, dIn, target.data(), target.size(), nullptr)); });
             if (nlmFilter) {                                                                    // single-frame NLM, :1577-1606 with one frame
                 mid_nlm_params p{w, h, opt.nlm_h, opt.search_lo, opt.search_hi, opt.patch_lo, opt.patch_hi, fmt};
                 const void *fr[1] = {dIn};
@@ -243,12 +267,13 @@ public:
                 std::vector<void *> dLayers;
                 for (auto &ln : layerNames) {
                     std::cout << "\t\tfeeding layer to texture\n";
-                    HostImage l = load(ln, true);
+                    HostImage l = load(ln, true, pin);
                     if (l.w != w || l.h != h) throw std::runtime_error(ln + ": layer size differs from the target image");
                     void *d = nullptr;
-                    MID_CHECK(mid_alloc(ctx, l.bytes.size(), &d));
+                    MID_CHECK(mid_alloc(ctx, l.size(), &d));
                     dLayers.push_back(d);
-                    timed(m_transferMs, [&] { MID_CHECK(mid_memcpy_h2d(ctx, d, l.bytes.data(), l.bytes.size(), nullptr)); });
+                    timed(m_transferMs, [&] { MID_CHECK(mid_memcpy_h2d(ctx, d, l.data(), l.size(), nullptr)); });
+                    MID_CHECK(mid_stream_sync(ctx, nullptr));             // `l` is released at the end of this iteration
                 }
                 mid_bilateral_params p{w, h, opt.sigma_s, opt.sigma_c, opt.radius, MID_LAYOUT_TEXTURE, fmt};
                 timed(m_execMs, [&] {
@@ -271,7 +296,7 @@ public:
         outputFileName += multiframe ? "-multiframe" : "";
         outputFileName += execAndCopyOverlap ? "-overlap" : "";
         outputFileName += useLayers ? "-layers" : "";
-        save(outputFileName, result, w, h, hdr);
+        save(outputFileName, result.data(), w, h, hdr);
         std::cout << "\tcleaning up\n";
     }
 
@@ -497,11 +522,11 @@ public:
         }
     }
 
-    void save(std::string name, const std::vector<Pixel> &px, int w, int h, bool hdr) const
+    void save(std::string name, const Pixel *px, int w, int h, bool hdr) const
     {
         if (hdr) {
             name += ".exr";
-            MID_CHECK(mid_image_save(out_path(name).c_str(), px.data(), w, h, MID_FMT_RGBA32F));     // SaveEXR :1699
+            MID_CHECK(mid_image_save(out_path(name).c_str(), px, w, h, MID_FMT_RGBA32F));     // SaveEXR :1699
         } else {
             name += ".png";
             std::cout << "\t\tencoding png\n";
@@ -523,20 +548,20 @@ public:
         std::vector<Pixel> inputPixels((size_t)w * h);
         if (img.format == MID_FMT_RGBA32F) {
             std::cout << "\tloading hdr\n";
-            memcpy((void *)inputPixels.data(), img.bytes.data(), img.bytes.size());
+            memcpy((void *)inputPixels.data(), img.data(), img.size());
         } else {
             for (size_t i = 0; i < (size_t)w * h; ++i) {                                              // :1804-1807
-                inputPixels[i].r = (float)img.bytes[4 * i + 0] * (1.0f / 255.0f);
-                inputPixels[i].g = (float)img.bytes[4 * i + 1] * (1.0f / 255.0f);
-                inputPixels[i].b = (float)img.bytes[4 * i + 2] * (1.0f / 255.0f);
-                inputPixels[i].a = (float)img.bytes[4 * i + 3] * (1.0f / 255.0f);
+                inputPixels[i].r = (float)img.data()[4 * i + 0] * (1.0f / 255.0f);
+                inputPixels[i].g = (float)img.data()[4 * i + 1] * (1.0f / 255.0f);
+                inputPixels[i].b = (float)img.data()[4 * i + 2] * (1.0f / 255.0f);
+                inputPixels[i].a = (float)img.data()[4 * i + 3] * (1.0f / 255.0f);
             }
         }
         std::cout << "\tdoing computations\n";
         std::vector<Pixel> outputPixels;
         cpu_bilateral_refpath(inputPixels, w, h, opt.cpu_radius, opt.cpu_sigma_s, opt.cpu_sigma_c, opt.cpu_blue_bug, numThreads, outputPixels);
         std::cout << "\tsaving image\n";
-        save("output-cpu", outputPixels, w, h, img.format == MID_FMT_RGBA32F);
+        save("output-cpu", outputPixels.data(), w, h, img.format == MID_FMT_RGBA32F);
     }
 };
 
@@ -562,6 +587,8 @@ static void usage()
         "  --share-device            animation mode: all --gpus N blocks run on --device (a rehearsal of the N-block schedule on fewer\n"
         "                            devices; with --halo rccl it needs a stand-in for RCCL, MID_RCCL_LIBRARY: RCCL itself refuses\n"
         "                            two ranks on one device)\n"
+        "  --pageable-host           the six GPU modes: decode into and read back to ordinary (not page-locked) memory; the library\n"
+        "                            then moves every copy through its own pinned bounce buffers -- same files, slower copies\n"
         "  --pinned-mb M             animation mode: page-lock at most M MiB of host memory for frames in and out (default 16384);\n"
         "                            frames beyond that, or whose page-locked allocation fails, use pageable memory\n"
         "  --cpu-radius R --cpu-sigma-s S --cpu-sigma-c C   CPU path (default 10 10.0 0.2)\n"
@@ -595,6 +622,7 @@ int main(int argc, char **argv)
         else if (a == "--gpus") opt.gpus = atoi(next());
         else if (a == "--share-device") opt.share_device = true;
         else if (a == "--pinned-mb") opt.pinned_mb = atol(next());
+        else if (a == "--pageable-host") opt.pageable_host = true;
         else if (a == "--halo") { const std::string v = next(); if (v == "rccl") opt.halo_rccl = true; else if (v != "host") { usage(); return EXIT_FAILURE; } }
         else if (a == "--cpu-radius") opt.cpu_radius = atoi(next());
         else if (a == "--cpu-sigma-s") opt.cpu_sigma_s = (float)atof(next());

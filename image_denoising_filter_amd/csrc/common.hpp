@@ -19,6 +19,17 @@ struct mid_pipe_cache {
     std::vector<hipEvent_t> ev;
 };
 
+// Page-locked bounce buffers for host memory the caller did NOT pin (csrc/hostcopy.cpp): two halves used alternately, each
+// guarded by the event of the last DMA that read or wrote it.  One set per direction, so the frame pipeline's upload and
+// download streams never wait on each other's chunks.  Allocated on the first pageable copy, freed with the context.
+struct mid_bounce {
+    std::mutex mu;                      // one pageable copy per direction at a time
+    void *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};      // ev[i] has been recorded and not yet waited for
+    size_t chunk = 0;
+};
+
 struct mid_ctx {
     int device;
     hipStream_t compute;   // default stream for kernels
@@ -33,6 +44,7 @@ struct mid_ctx {
     std::mutex mu;
     std::unordered_set<const void *> lds_configured;
     mid_pipe_cache pipe;
+    mid_bounce bounce_up, bounce_down;   // pageable host memory never reaches hipMemcpyAsync: see csrc/hostcopy.cpp
 };
 
 namespace mid {
@@ -63,6 +75,15 @@ inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
 // Frees what the frame pipeline keeps in the context (pipeline.cpp); the context's streams must be idle.
 void pipe_cache_release(mid_ctx *ctx);
+
+// Host <-> device copies that never hand the runtime pageable memory (csrc/hostcopy.cpp).  Pinned host memory
+// (hipHostMalloc / hipHostRegister: mid_alloc_host, mid_host_register, mid_image_load_pinned) is DMA'd in place and the
+// call is asynchronous on `s`; anything else goes through the context's page-locked bounce buffers in chunks: copy_h2d
+// returns when the source has been consumed (the last DMAs may still be in flight on `s`), copy_d2h when the data is in dst.
+bool host_is_pinned(const void *p, size_t bytes);
+int copy_h2d(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t s);
+int copy_d2h(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t s);
+void bounce_release(mid_ctx *ctx);     // waits for the last chunks and frees both bounce sets
 
 // mid_nlm_temporal with the output format as an argument: out_u8 != 0 writes RGBA8 frames (pack_rgba8 of the
 // normalized pixel) instead of float4 ones -- used by the frame pipeline's u8 variant, not exported.

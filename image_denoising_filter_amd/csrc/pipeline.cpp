@@ -17,8 +17,9 @@
 // downloads up to three behind: the stages are decoupled and the slowest one (measured: the
 // 33 MB/frame download, 0.70 ms) sets the frame rate.  This is the ONE schedule the library ships
 // (a gated chunk-launch alternative was measured in round 2 and removed: LABNOTES.md).  Host frames
-// allocated with mid_alloc_host (pinned) are DMA'd directly; pageable memory still works but
-// HIP stages it and the overlap is lost.
+// allocated with mid_alloc_host (pinned) are DMA'd directly; pageable memory still works, but it is
+// moved through the context's page-locked bounce buffers (csrc/hostcopy.cpp: a host memcpy per 8 MiB
+// chunk, never the runtime's pin-on-the-fly path) and the host thread -- not the link -- sets the pace.
 //
 // Frame selection differs from the reference on purpose: frames are taken
 // in the order given, window t-k..t+k clipped at the sequence ends; the reference's "every
@@ -137,8 +138,23 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
             }
         }
         MID_HIP(hipEventRecord(up0.ev[f - f_lo], ctx->upload));
-        MID_HIP(hipMemcpyAsync(slot(f), host_frames[f], in_bytes, hipMemcpyHostToDevice, ctx->upload));
+        if (int rc = copy_h2d(ctx, slot(f), host_frames[f], in_bytes, ctx->upload)) return rc;
         MID_HIP(hipEventRecord(up1.ev[f - f_lo], ctx->upload));
+        return MID_OK;
+    };
+    // Pinned outputs: download(bi) is queued right behind compute(bi) and the host runs on.  Pageable outputs: copy_d2h
+    // returns only when the frame is in the caller's buffer, so download(bi) is issued one iteration late -- after
+    // compute(bi+1) and its uploads have been queued -- and the GPU keeps a launch in flight while the host copies out.
+    // d1[bi] is then recorded in iteration bi+1, still before compute(bi+DEPTH) asks for it.
+    bool out_pinned = true;
+    for (int i = 0; i < count; ++i) out_pinned = out_pinned && host_is_pinned(host_out[i], dl_bytes);
+    auto download = [&](int bi) -> int {
+        const int b0 = first + bi * B, bn = (first + count - b0) < B ? (first + count - b0) : B;
+        MID_HIP(hipStreamWaitEvent(ctx->download, c1.ev[bi], 0));
+        MID_HIP(hipEventRecord(d0.ev[bi], ctx->download));
+        for (int i = 0; i < bn; ++i)
+            if (int rc = copy_d2h(ctx, host_out[b0 - first + i], dout.p[(bi % DEPTH) * B + i], dl_bytes, ctx->download)) return rc;
+        MID_HIP(hipEventRecord(d1.ev[bi], ctx->download));
         return MID_OK;
     };
 
@@ -174,11 +190,8 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
 
         while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }
 
-        MID_HIP(hipStreamWaitEvent(ctx->download, c1.ev[bi], 0));
-        MID_HIP(hipEventRecord(d0.ev[bi], ctx->download));
-        for (int i = 0; i < bn; ++i)
-            MID_HIP(hipMemcpyAsync(host_out[b0 - first + i], dout.p[(bi % DEPTH) * B + i], dl_bytes, hipMemcpyDeviceToHost, ctx->download));
-        MID_HIP(hipEventRecord(d1.ev[bi], ctx->download));
+        if (out_pinned || !overlap) { if (int rc = download(bi)) return rc; }
+        else if (bi >= 1) { if (int rc = download(bi - 1)) return rc; }
 
         if (!overlap) {   // the reference's behaviour: a fence wait after every submit (src/main.cpp:1092)
             MID_HIP(hipStreamSynchronize(ctx->upload));
@@ -186,6 +199,7 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
             MID_HIP(hipStreamSynchronize(ctx->download));
         }
     }
+    if (!out_pinned && overlap) { if (int rc = download(nb - 1)) return rc; }
     MID_HIP(hipStreamSynchronize(ctx->upload));
     MID_HIP(hipStreamSynchronize(ctx->compute));
     MID_HIP(hipStreamSynchronize(ctx->compute2));
@@ -254,7 +268,7 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
 
     // target + cleared weight buffer (the reference relies on a fresh allocation being zero)
     MID_HIP(hipEventRecord(misc.ev[0], ctx->upload));
-    MID_HIP(hipMemcpyAsync(dtarget.p[0], host_target, in_bytes, hipMemcpyHostToDevice, ctx->upload));
+    if (int rc = copy_h2d(ctx, dtarget.p[0], host_target, in_bytes, ctx->upload)) return rc;
     MID_HIP(hipEventRecord(misc.ev[1], ctx->upload));
     MID_HIP(hipMemsetAsync(dW.p[0], 0, npix * sizeof(mid_weightinfo), ctx->compute));
     MID_HIP(hipStreamWaitEvent(ctx->compute, misc.ev[1], 0));
@@ -262,7 +276,7 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
     auto upload = [&](int f) -> int {
         if (f >= SLOTS) MID_HIP(hipStreamWaitEvent(ctx->upload, c1.ev[f - SLOTS], 0));   // slot still read by dispatch f-SLOTS
         MID_HIP(hipEventRecord(up0.ev[f], ctx->upload));
-        MID_HIP(hipMemcpyAsync(dslot.p[f % SLOTS], host_frames[f], in_bytes, hipMemcpyHostToDevice, ctx->upload));
+        if (int rc = copy_h2d(ctx, dslot.p[f % SLOTS], host_frames[f], in_bytes, ctx->upload)) return rc;
         MID_HIP(hipEventRecord(up1.ev[f], ctx->upload));
         return MID_OK;
     };
@@ -283,7 +297,7 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
     mid_normalize_params np{p->width, p->height};
     if (int rc = mid_normalize(ctx, &np, (const mid_weightinfo *)dW.p[0], (mid_pixel *)dout.p[0], ctx->compute)) return rc;
     MID_HIP(hipEventRecord(misc.ev[2], ctx->compute));
-    MID_HIP(hipMemcpyAsync(host_out, dout.p[0], out_bytes, hipMemcpyDeviceToHost, ctx->compute));
+    if (int rc = copy_d2h(ctx, host_out, dout.p[0], out_bytes, ctx->compute)) return rc;
     MID_HIP(hipEventRecord(misc.ev[3], ctx->compute));
     MID_HIP(hipStreamSynchronize(ctx->upload));
     MID_HIP(hipStreamSynchronize(ctx->compute));

@@ -108,6 +108,9 @@ _SIGNATURES = {
     "mid_comm_loopback": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
     "mid_nlm_temporal_sharded": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), c_void_pp, ctypes.c_int, ctypes.c_int, c_void_pp, _P]),
     "mid_comm_last_exchange": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_float)]),
+    "mid_comm_last_timeline": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
+    "mid_comm_last_issue_order": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),
+    "mid_comm_stream_priority": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mid_image_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Image)]),
     "mid_image_free": (None, [ctypes.POINTER(Image)]),
     "mid_image_load_pinned": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(Image)]),

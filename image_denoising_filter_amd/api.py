@@ -476,3 +476,27 @@ class Comm:
         a, b, ms = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_float()
         _check(lib.mid_comm_last_exchange(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(ms)), "mid_comm_last_exchange")
         return a.value, b.value, ms.value
+
+    def last_timeline(self):
+        """Device timeline of the last sharded call (mid_comm_last_timeline; waits for the call), ms from its first event:
+        dict(exchange_start, exchange_end, interior_end, end, halo_hidden_frac).  halo_hidden_frac is the share of the
+        exchange that ran while interior launches were still executing (None when nothing was exchanged)."""
+        t = (ctypes.c_float * 4)()
+        _check(lib.mid_comm_last_timeline(self.handle, t), "mid_comm_last_timeline")
+        x0, x1, i1, end = (float(v) for v in t)
+        hidden = None
+        if x1 > x0:
+            hidden = max(0.0, min(1.0, (min(x1, i1) - x0) / (x1 - x0)))
+        return {"exchange_start_ms": x0, "exchange_end_ms": x1, "interior_end_ms": i1, "end_ms": end, "halo_hidden_frac": hidden}
+
+    def last_issue_order(self):
+        """'X' exchange group, 'I' interior launch, 'W' wait for the exchange, 'B' boundary launch -- in host issue order."""
+        buf = ctypes.create_string_buffer(64)
+        _check(lib.mid_comm_last_issue_order(self.handle, buf, 64), "mid_comm_last_issue_order")
+        return buf.value.decode()
+
+    def stream_priority(self):
+        """(priority of the exchange stream, least, greatest) -- numerically lower is higher."""
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(lib.mid_comm_stream_priority(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "mid_comm_stream_priority")
+        return a.value, b.value, c.value

@@ -183,9 +183,13 @@ struct mid_comm {
     mid_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
-    hipStream_t xs = nullptr;               // exchange stream
+    hipStream_t xs = nullptr;               // exchange stream (highest priority the device offers: see comm_finish_create)
+    int xs_priority = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr, x0 = nullptr;
+    hipEvent_t i1 = nullptr;                // end of the interior launches on the caller's stream (timeline only)
     hipEvent_t done = nullptr;              // end of the last sharded call's launches, on the stream it was issued on
+    bool have_i1 = false, have_done = false;
+    std::string issued;                     // host-side issue order of the last call: X I.. W B.. (mid_comm_last_issue_order)
     hipStream_t last_stream = nullptr;      // that stream (valid while has_last)
     bool has_last = false;
     std::vector<void *> halo;               // device buffers for received frames, grown on demand
@@ -196,13 +200,23 @@ struct mid_comm {
     std::atomic<bool> aborted{false};       // set by mid_comm_abort, possibly from another thread than the one inside a call
 };
 
+// The exchange stream gets the HIGHEST priority the device offers.  RCCL's send/receive are kernels (a few workgroups
+// per channel) that must find compute units beside an interior NLM launch of thousands of workgroups already queued on
+// the caller's stream; at equal priority the hardware scheduler may serve them only as interior workgroups retire, and
+// the halo -- which the boundary launches wait for -- would arrive late for no reason.  Priority only orders dispatch
+// of WAITING workgroups, it pre-empts nothing, so the interior launch loses at most the few CUs the transport needs.
+// Whether this hides the exchange completely is what mid_comm_last_timeline reports on the first multi-GPU run.
 static int comm_finish_create(mid_comm *c)
 {
-    MID_HIP(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
-    MID_HIP(hipEventCreateWithFlags(&c->e0, hipEventDisableTiming));
+    int least = 0, greatest = 0;
+    MID_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));         // numerically lower = higher priority
+    c->xs_priority = greatest;
+    MID_HIP(hipStreamCreateWithPriority(&c->xs, hipStreamNonBlocking, greatest));
+    MID_HIP(hipEventCreate(&c->e0));
     MID_HIP(hipEventCreate(&c->e1));
     MID_HIP(hipEventCreate(&c->x0));
-    MID_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    MID_HIP(hipEventCreate(&c->i1));
+    MID_HIP(hipEventCreate(&c->done));
     return MID_OK;
 }
 
@@ -322,6 +336,7 @@ extern "C" int mid_comm_destroy(mid_comm *c)
     if (c->e0) (void)hipEventDestroy(c->e0);
     if (c->e1) (void)hipEventDestroy(c->e1);
     if (c->x0) (void)hipEventDestroy(c->x0);
+    if (c->i1) (void)hipEventDestroy(c->i1);
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->xs) (void)hipStreamDestroy(c->xs);
     delete c;
@@ -404,15 +419,31 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
 
     std::vector<Xfer> rv, sd;
     if (c->world > 1) halo_plan(n_frames, c->world, k, c->rank, rv, sd);
-    c->last_recv = rv.size() * frame_bytes; c->last_sent = sd.size() * frame_bytes; c->timed = false;
+    c->last_recv = rv.size() * frame_bytes; c->last_sent = sd.size() * frame_bytes;
+    c->timed = false; c->have_i1 = false; c->have_done = false; c->issued.clear();
 
     // receive buffers (kept across calls; a call's receives are ordered after the previous call's last readers through
-    // e0 on the one stream the stream rule above enforces).  Last local step that can fail: nothing below this line
-    // returns before the exchange has been issued, except an RCCL error itself.
+    // e0 on the one stream the stream rule above enforces).  This is the last step that can fail for a LOCAL reason
+    // (out of memory); after it only a HIP call on a broken device or RCCL itself can make the rank return early.
     if (int rc = reserve_halo(c, frame_bytes, rv.size())) return rc;
 
+    // From the first thing queued on the caller's stream, however this call ends -- a launch that fails half way through
+    // the plan, a HIP error after the group was closed -- `done` is recorded behind whatever WAS queued and
+    // last_stream/has_last name this call: the stream rule of the next call and reserve_halo's "may the retired buffers
+    // be freed" then test this call's work, not an older call's.
+    struct Finish {
+        mid_comm *c; hipStream_t s; bool armed = false;
+        ~Finish()
+        {
+            if (!armed) return;
+            c->have_done = hipEventRecord(c->done, s) == hipSuccess;
+            c->last_stream = s; c->has_last = true;
+        }
+    } finish{c, b.s};
+
+    MID_HIP(hipEventRecord(c->e0, b.s));                           // t = 0 of the timeline; the block's frames (and the halo buffers' last readers) are done
+    finish.armed = true;
     if (!rv.empty() || !sd.empty()) {
-        MID_HIP(hipEventRecord(c->e0, b.s));                       // the block's frames (and the halo buffers' last readers) are done
         MID_HIP(hipStreamWaitEvent(c->xs, c->e0, 0));
         MID_HIP(hipEventRecord(c->x0, c->xs));
         MID_NCCL(rccl().GroupStart());
@@ -424,12 +455,9 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
             return set_error(MID_ERR_HIP, "halo exchange: %s", rccl().GetErrorString(bad != ncclSuccess ? bad : end));
         MID_HIP(hipEventRecord(c->e1, c->xs));
         c->timed = true;
+        c->issued += 'X';
     }
-    if (count == 0) {
-        MID_HIP(hipEventRecord(c->done, b.s));
-        c->last_stream = b.s; c->has_last = true;
-        return MID_OK;
-    }
+    if (count == 0) return MID_OK;
 
     std::vector<Launch> plan;
     launch_plan(n_frames, c->world, k, c->rank, plan);
@@ -439,7 +467,12 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
         return nullptr;
     };
     for (int phase = 1; phase >= 0; --phase) {                    // interior launches first, then (after the halo) the boundary ones
-        if (phase == 0 && c->timed) MID_HIP(hipStreamWaitEvent(b.s, c->e1, 0));
+        if (phase == 0) {
+            // every interior launch is on the stream by now; only here is the stream told to wait for the exchange
+            MID_HIP(hipEventRecord(c->i1, b.s));
+            c->have_i1 = true;
+            if (c->timed) { MID_HIP(hipStreamWaitEvent(b.s, c->e1, 0)); c->issued += 'W'; }
+        }
         for (const Launch &L : plan) {
             if (L.interior != phase) continue;
             std::vector<const void *> tbl(L.w_hi - L.w_lo + 1);
@@ -448,11 +481,10 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
                 MID_REQUIRE(tbl[f - L.w_lo], "nlm_temporal_sharded: frame %d is neither in the block nor in the halo (plan error)", f);
             }
             if (int rc = mid_nlm_temporal(c->ctx, p, tbl.data(), (int)tbl.size(), k, L.first, L.count, out + L.off, b.s)) return rc;
+            c->issued += phase ? 'I' : 'B';
         }
     }
-    MID_HIP(hipEventRecord(c->done, b.s));
-    c->last_stream = b.s; c->has_last = true;
-    return MID_OK;
+    return MID_OK;                                                 // (`finish` records `done`)
 }
 
 extern "C" int mid_comm_last_exchange(mid_comm *c, size_t *bytes_recv, size_t *bytes_sent, float *exchange_ms)
@@ -469,5 +501,50 @@ extern "C" int mid_comm_last_exchange(mid_comm *c, size_t *bytes_recv, size_t *b
             MID_HIP(hipEventElapsedTime(exchange_ms, c->x0, c->e1));
         }
     }
+    return MID_OK;
+}
+
+// Device timeline of the last sharded call, ms from its first event on the caller's stream: [0] exchange start, [1] exchange
+// end (0, 0 when nothing was exchanged), [2] end of the interior launches, [3] end of the call's last launch.  The share of
+// the exchange that ran while interior launches were still executing is (min(t1, t2) - t0) / (t1 - t0), clamped to [0, 1].
+extern "C" int mid_comm_last_timeline(mid_comm *c, float t_ms[4])
+{
+    MID_REQUIRE(c && t_ms, "comm_last_timeline: NULL argument");
+    t_ms[0] = t_ms[1] = t_ms[2] = t_ms[3] = 0.f;
+    if (!c->has_last || !c->have_done) return MID_OK;
+    Bind b(c->ctx, nullptr);
+    if (b.rc) return b.rc;
+    MID_HIP(hipEventSynchronize(c->done));
+    if (c->timed) {
+        MID_HIP(hipEventSynchronize(c->e1));
+        MID_HIP(hipEventElapsedTime(&t_ms[0], c->e0, c->x0));
+        MID_HIP(hipEventElapsedTime(&t_ms[1], c->e0, c->e1));
+    }
+    if (c->have_i1) MID_HIP(hipEventElapsedTime(&t_ms[2], c->e0, c->i1));
+    MID_HIP(hipEventElapsedTime(&t_ms[3], c->e0, c->done));
+    return MID_OK;
+}
+
+// What the last sharded call put on its streams, in host issue order: 'X' the exchange group (exchange stream), 'I' an
+// interior launch, 'W' the launch stream's wait for the exchange, 'B' a boundary launch.  The overlap of halo and interior
+// compute is structural when every 'I' precedes the 'W' (tests/test_gpu_sharded_multirank.py asserts it).
+extern "C" int mid_comm_last_issue_order(mid_comm *c, char *buf, size_t buflen)
+{
+    MID_REQUIRE(c && buf && buflen > 0, "comm_last_issue_order: bad argument");
+    snprintf(buf, buflen, "%s", c->issued.c_str());
+    return MID_OK;
+}
+
+extern "C" int mid_comm_stream_priority(mid_comm *c, int *priority, int *least, int *greatest)
+{
+    MID_REQUIRE(c != nullptr, "comm_stream_priority: comm is NULL");
+    Bind b(c->ctx, nullptr);
+    if (b.rc) return b.rc;
+    int lo = 0, hi = 0, pr = 0;
+    MID_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    MID_HIP(hipStreamGetPriority(c->xs, &pr));
+    if (priority) *priority = pr;
+    if (least) *least = lo;
+    if (greatest) *greatest = hi;
     return MID_OK;
 }

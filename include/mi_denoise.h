@@ -117,11 +117,18 @@ int mid_free_host(mid_ctx *ctx, void *hptr);
 /* Pin memory the caller already owns (a decoded frame in a std::vector, say) so that copies from/to it are truly
  * asynchronous (the pinning holds for every device of the process); undo with mid_host_unregister before the memory is
  * freed and after every copy that uses it has completed.  Measured on MI355X, 16 x 1080p RGBA32F through
- * mid_sequence_nlm: buffers from mid_alloc_host 12.8 ms, pageable memory (HIP stages it) 20.2 ms, memory registered in
- * place 25.1 ms (+6 ms to register) -- so decode into mid_alloc_host buffers when throughput matters, and register in
- * place only when the calling thread must not block in the copy. */
+ * mid_sequence_nlm: buffers from mid_alloc_host 12.8 ms, memory registered in place 25.1 ms (+6 ms to register), pageable
+ * memory (bounced inside the library, see mid_memcpy_h2d) slower than either -- so decode into mid_alloc_host buffers when
+ * throughput matters, and register in place when the frames already exist in ordinary memory. */
 int mid_host_register(mid_ctx *ctx, void *hptr, size_t bytes);
 int mid_host_unregister(mid_ctx *ctx, void *hptr);
+/* Host <-> device copies.  Page-locked host memory (mid_alloc_host, mid_host_register, mid_image_load_pinned) is DMA'd in
+ * place and the call is asynchronous on `stream`.  ANY OTHER host memory is accepted too, but it never reaches the HIP
+ * runtime (whose pin-on-the-fly path for pageable copies of more than 1 MiB the library does not rely on): it is moved in
+ * 8 MiB chunks through page-locked bounce buffers the context owns (32 MiB, allocated on first use), and the call returns
+ * when src_host has been consumed (h2d; the last chunks may still be in flight on `stream`) or dst_host holds the data (d2h).
+ * The same holds for every host frame handed to mid_sequence_nlm* / mid_nlm_multiframe.  Pageable copies cost a host memcpy
+ * on top of the DMA (measured: see LABNOTES R5.1), so decode into pinned memory when throughput matters. */
 int mid_memcpy_h2d(mid_ctx *ctx, void *dst, const void *src_host, size_t bytes, void *stream);  /* LoadImageDataToBuffer + copy-to-texture, src/main.cpp:1105-1142,990-1076 */
 int mid_memcpy_d2h(mid_ctx *ctx, void *dst_host, const void *src, size_t bytes, void *stream);  /* vkCmdCopyBuffer to staging + GetImageFromGPU, src/main.cpp:835-840,91-123 */
 int mid_memset(mid_ctx *ctx, void *dst, int value, size_t bytes, void *stream);                 /* the reference never clears its weight buffer; callers of *_accum must */
@@ -256,7 +263,14 @@ int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const void *host_t
  * mid_comm_abort: ncclCommAbort -- tears the rank's connections down without waiting for outstanding operations; the
  *   handle then only accepts mid_comm_destroy.
  * mid_comm_loopback: a send+receive addressed to this very rank (the exchange's call pattern without the wire).
- * mid_comm_last_exchange: bytes received/sent by the last sharded call and (waits for it) the exchange's duration. */
+ * mid_comm_last_exchange: bytes received/sent by the last sharded call and (waits for it) the exchange's duration.
+ * mid_comm_last_timeline: (waits for the call) its device timeline in ms from the call's first event on the caller's stream:
+ *   t[0] exchange start, t[1] exchange end (both 0 when nothing was exchanged), t[2] end of the interior launches, t[3] end of
+ *   the last launch.  The share of the exchange hidden behind interior compute is (min(t[1], t[2]) - t[0]) / (t[1] - t[0]).
+ * mid_comm_last_issue_order: what the call put on its streams, in host issue order -- 'X' exchange group, 'I' interior
+ *   launch, 'W' the launch stream's wait for the exchange, 'B' boundary launch; every 'I' precedes the 'W' by construction.
+ * mid_comm_stream_priority: the exchange stream's priority and the device's range (numerically lower = higher); the stream
+ *   is created with the highest, so RCCL's send/receive kernels are dispatched ahead of queued interior workgroups. */
 typedef struct mid_comm mid_comm;
 #define MID_COMM_ID_BYTES 128
 int mid_shard_block(int n_frames, int world, int rank, int *start, int *count);
@@ -274,6 +288,9 @@ int mid_comm_loopback(mid_comm *comm, const void *src, void *dst, size_t bytes, 
 int mid_nlm_temporal_sharded(mid_comm *comm, const mid_nlm_params *p, const void *const *block /* count device frames */,
                              int n_frames, int k, mid_pixel *const *out /* count device frames */, void *stream);
 int mid_comm_last_exchange(mid_comm *comm, size_t *bytes_recv, size_t *bytes_sent, float *exchange_ms);
+int mid_comm_last_timeline(mid_comm *comm, float t_ms[4]);
+int mid_comm_last_issue_order(mid_comm *comm, char *buf, size_t buflen);
+int mid_comm_stream_priority(mid_comm *comm, int *priority, int *least, int *greatest);
 
 /* ---- 8f-2: image files ------------------------------------------------------------------
  * mid_image_load = LoadImages (src/main.cpp:145-229): ".exr" -> RGBA32F (tinyexr LoadEXR: missing

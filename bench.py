@@ -45,6 +45,7 @@ BIL_BYTES_PER_PX = 32
 PEAK_FP32_TFLOPS = 157.3                  # MI355X_MICROARCH.md: fp32 vector = dense f32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 SEQ_FRAMES = 64                           # BASELINE configs[4]: one 64-frame animation, temporal +-2
+WATCHDOG_S = 300.0                        # the side measurements after the timed region may take this long before the line is forced out
 
 
 def synth_frames(n, seed, device, shift=0):
@@ -67,27 +68,58 @@ def synth_frames(n, seed, device, shift=0):
     return out
 
 
-def load_traffic(frames_per_launch):
+def loaded_kernel_fingerprint(lib_path, workload):
+    """sha256 of the timed kernel's machine code in the library this process has LOADED (function bytes + kernel descriptor,
+    image_denoising_filter_amd/_codeobj.py), or (None, reason).  The counter figures below are only read back from
+    profiles/ when the profile was taken on a kernel with the same fingerprint."""
+    try:
+        from image_denoising_filter_amd import _codeobj
+        if workload not in _codeobj.BENCH_KERNELS:
+            return None, f"no fingerprint defined for workload {workload!r}"
+        return _codeobj.fingerprint(lib_path, workload)["kernel_code_sha256"], None
+    except Exception as e:  # noqa: BLE001
+        return None, f"fingerprint of the loaded library failed: {e}"
+
+
+def _same_code(profile, key, name, fp):
+    """None when the profile `name` was taken on the kernel this run has loaded, else the reason it may not be read back."""
+    digest, why = fp
+    if digest is None:
+        return why
+    if not profile.get(key):
+        return f"{name} carries no kernel fingerprint (taken before round 5): refusing to read counters of an unidentified kernel back"
+    if profile[key] != digest:
+        return (f"{name} was measured on kernel code {profile[key][:12]}..., the loaded library holds {digest[:12]}...: "
+                "the kernel changed after the profile -- refresh with tools/run_profiles.sh")
+    return None
+
+
+def load_traffic(frames_per_launch, fp):
     """(HBM bytes per launch, where that figure comes from).  PMC counters cannot be read from inside an
     un-profiled run, so the figure is the one measured by the committed rocprofv3 `--pmc` passes of this same
     command (profiles/*_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); `traffic_source` in the JSON
-    line says so, with the file and its date.  (None, reason) when no profile matches the launch shape."""
+    line says so, with the file and its date.  (None, reason) when no profile matches the launch shape or the
+    profile was taken on different kernel code than the library now loaded holds (`fp`)."""
     import glob
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not cands:
         return None, "no profiles/r*_traffic.json"
     try:
         t = json.load(open(cands[-1]))
+        stale = _same_code(t, "kernel_code_sha256", os.path.basename(cands[-1]), fp)
+        if stale:
+            return None, stale
         if t.get("algorithmic_bytes_per_launch") != frames_per_launch * NPIX * NLM_BYTES_PER_PX:
             return None, f"{os.path.basename(cands[-1])} was measured for a different launch shape"
         when = t.get("date") or time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(cands[-1])))
         return round(t["traffic_bytes_per_launch"]), (f"profiles/{os.path.basename(cands[-1])} ({when}): rocprofv3 --pmc FETCH_SIZE / "
-                                                     "WRITE_SIZE passes of this command, read back -- not measured in this run")
+                                                     "WRITE_SIZE passes of this command, read back -- not measured in this run; "
+                                                     f"kernel code sha256 {t['kernel_code_sha256'][:12]}... matches the loaded library")
     except Exception as e:  # noqa: BLE001
         return None, f"unreadable profile: {e}"
 
 
-def load_utilisation(workload):
+def load_utilisation(workload, fp):
     """Counter-derived utilisation of the dominant kernel (VALU issue, LDS, stall share), read back from the committed
     profiles/r*_utilisation.json exactly like `traffic` -- PMC counters cannot be read inside an un-profiled run.
     tools/summarize_profiles.py writes that file from the rocprofv3 --pmc passes of this command and states every
@@ -98,6 +130,10 @@ def load_utilisation(workload):
         return {"valu_util": None, "lds_util": None, "utilisation_source": "no profiles/r*_utilisation.json"}
     try:
         u = json.load(open(cands[-1]))
+        if workload == "nlm":
+            stale = _same_code(u, "bench_kernel_code_sha256", os.path.basename(cands[-1]), fp)
+            if stale:
+                return {"valu_util": None, "lds_util": None, "utilisation_source": stale}
         k = u["kernels"]["nlm_bench" if workload == "nlm" else "bilateral_r8_linear"]
         return {"valu_util": k["valu_issue_util"], "valu_util_at_occupancy_prices": k.get("valu_issue_util_at_occupancy"),
                 "cycles_per_wave_offset": {q: k["cycles_per_wave_offset"][q] for q in ("measured", "floor", "at_occupancy_prices")} if k.get("cycles_per_wave_offset") else None,
@@ -142,38 +178,69 @@ class Timers:
         self.t = []
 
 
+def synth_c1(seed=1):
+    """SURVEY.md 8d C1 = BASELINE configs[0]: 512x512 RGBA8, smooth gradient + 3 hard-edged discs + Gaussian noise sigma 10/255."""
+    rng = np.random.default_rng(seed)
+    n = 512
+    yy, xx = np.mgrid[0:n, 0:n].astype(np.float32)
+    img = np.stack([xx / (n - 1), yy / (n - 1), 0.5 + 0.25 * (xx + yy) / (n - 1)], -1)
+    for cx, cy, r, col in ((0.3, 0.35, 0.16, (0.9, 0.2, 0.1)), (0.7, 0.6, 0.2, (0.1, 0.8, 0.3)), (0.45, 0.8, 0.1, (0.2, 0.3, 0.9))):
+        img[(xx - cx * n) ** 2 + (yy - cy * n) ** 2 < (r * n) ** 2] = col
+    img = np.clip(img + rng.normal(0, 10 / 255, img.shape), 0, 1)
+    return (np.concatenate([img, np.ones((n, n, 1))], -1) * 255).astype(np.uint8)
+
+
 def _cpu_reference_bilateral(oracle):
-    """The reference's own CPU bilateral loop (oracle/_ref, src/main.cpp:1827-1864, r=10, sigma 10/0.2,
-    OpenMP over x) on this host's cores; bounded sample.  The only CPU code path the reference has.
+    """The reference's own CPU bilateral loop (oracle/_ref, src/main.cpp:1827-1864, sigma 10/0.2 are literals of the slice,
+    OpenMP over x) on this host's cores -- the only CPU code path the reference has.  SURVEY.md 8d's legs, each a bounded
+    sample (the whole table stays inside ~20 s):
+      C1  = BASELINE configs[0]: the 512x512 RGBA8 image decoded as RunOnCPU decodes it (c * (1/255), src/main.cpp:1804-1807), r = 4;
+      C2  = a strip of the 1920x1080 RGBA32F frame at r = 8 (like for like with the GPU bilateral of configs[1]) and at r = 10
+            (the reference's default windowSize, src/main.cpp:1819);
+      threads in {1, 8 (the reference's two choices, src/main.cpp:1979,1984), all cores of this box's share}.
+    The headline fields (value, cores, sample) stay what they were: r = 10, 8 threads, on a 1920x360 strip.
     `oracle` is the checker module, handed in by cpu_baseline() -- the one place that imports it."""
-    threads = min(8, os.cpu_count() or 1)          # the reference's own choice is 8 (src/main.cpp:1984)
-    rng = np.random.default_rng(1)
-    rows = 360                                     # a 1920x360 strip: ~1/3 frame, a few seconds of CPU work
-    img = (rng.random((rows, W, 4), dtype=np.float32) * 4).astype(np.float32)
     kind = "reference" if oracle.have_ref() else "port"
-    fn = (lambda: oracle.ref_cpu_bilateral(img, 10, threads)) if kind == "reference" else \
-         (lambda: oracle.cpu_bilateral(img, 10, 10.0, 0.2, True, threads))
-    fn()
-    ts = []
-    t_all = time.perf_counter()
-    while len(ts) < 3 and time.perf_counter() - t_all < 15:
-        t0 = time.perf_counter()
-        fn()
-        ts.append(time.perf_counter() - t0)
-    med = sorted(ts)[len(ts) // 2]
-    # the reference's other choice (1 thread, src/main.cpp:1979) and all host cores, on a thinner strip
-    other = {}
-    small = img[:60].copy()
-    for th in (1, min(os.cpu_count() or 1, 16)):     # 16 = the CPU share of a one-GPU box
-        f2 = (lambda: oracle.ref_cpu_bilateral(small, 10, th)) if kind == "reference" else \
-             (lambda: oracle.cpu_bilateral(small, 10, 10.0, 0.2, True, th))
-        t0 = time.perf_counter()
-        f2()
-        other[str(th)] = round(60 * W / 1e6 / (time.perf_counter() - t0), 4)
-    return {"value": round(rows * W / 1e6 / med, 4), "unit": "Mpixel/s", "cores": threads, "kind": kind,
-            "other_thread_counts_Mpixel/s": other,
-            "sample": f"reference CPU bilateral loop (r=10, sigma_s=10, sigma_c=0.2, {threads} OpenMP threads, -O2) "
-                      f"on a 1920x{rows} RGBA32F strip, median of {len(ts)} runs"}
+
+    def run(img, radius, threads):
+        if kind == "reference":
+            return oracle.ref_cpu_bilateral(img, radius, threads)
+        return oracle.cpu_bilateral(img, radius, 10.0, 0.2, True, threads)
+
+    nproc = min(os.cpu_count() or 1, 16)              # 16 = the CPU share of a one-GPU box
+    thread_set = sorted({1, min(8, nproc), nproc})
+    rng = np.random.default_rng(1)
+    frame = (rng.random((360, W, 4), dtype=np.float32) * 4).astype(np.float32)
+    c1 = oracle.unpack_u8(synth_c1(), flavour=1)      # CPU decode flavour: (float)c * (1.0f / 255.0f)
+    run(frame[:40], 4, nproc)                         # OpenMP team start-up, page faults
+    legs = []
+
+    def leg(name, img, radius, threads, budget_s, min_runs=1, max_runs=3):
+        ts = []
+        t_all = time.perf_counter()
+        while len(ts) < min_runs or (len(ts) < max_runs and time.perf_counter() - t_all < budget_s):
+            t0 = time.perf_counter()
+            run(img, radius, threads)
+            ts.append(time.perf_counter() - t0)
+        med = sorted(ts)[len(ts) // 2]
+        h_, w_ = img.shape[:2]
+        legs.append({"input": name, "radius": radius, "threads": threads, "Mpixel/s": round(h_ * w_ / 1e6 / med, 4),
+                     "sample_pixels": h_ * w_, "runs": len(ts), "seconds_per_run": round(med, 4)})
+        return legs[-1]
+
+    # rows per leg sized so that one run is ~0.3-1 s at the rates this loop reaches (0.2 Mpx/s per thread at r=10; cost ~ taps)
+    for th in thread_set:
+        leg("C1 512x512 RGBA8 (configs[0]), whole image", c1, 4, th, 1.5)
+    for radius, taps in ((8, 289), (10, 441)):
+        for th in thread_set:
+            rows = 360 if th == min(8, nproc) and radius == 10 else max(2 * radius + 8, min(360, int(0.2 * th * 441 / taps * 0.6e6 / W) // 4 * 4))
+            leg(f"C2 1920x{rows} RGBA32F strip of the 1080p frame", frame[:rows], radius, th, 2.5)
+    head = [l for l in legs if l["radius"] == 10 and l["threads"] == min(8, nproc)][0]
+    return {"value": head["Mpixel/s"], "unit": "Mpixel/s", "cores": head["threads"], "kind": kind,
+            "legs": legs,
+            "sample": f"reference CPU bilateral loop (r=10, sigma_s=10, sigma_c=0.2, {head['threads']} OpenMP threads, -O2) "
+                      f"on a 1920x360 RGBA32F strip, median of {head['runs']} runs; `legs` = SURVEY 8d's table "
+                      "(C1 r=4, C2 r=8 and r=10, threads 1 / 8 / all)"}
 
 
 def cpu_baseline(workload="nlm"):
@@ -227,8 +294,6 @@ def dry_run(args, json_out):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         world = dist.get_world_size()
-    if os.environ.get("MID_BENCH_TEST_FAIL_RANK") == str(rank):      # tests/test_bench_dryrun.py: a rank that dies
-        os._exit(7)
     h, w, F, k = 12, 20, args.frames, 2
     g = torch.Generator().manual_seed(100 + rank)
     frames = [torch.rand((h, w, 4), generator=g) for _ in range(F)]
@@ -464,7 +529,8 @@ def main():
     value = world * F * args.steps * NPIX / 1e6 / elapsed
     px_per_launch = F * NPIX // launches_per_step
     avg_launch_s /= launches_per_step        # the timers bracket one step = launches_per_step back-to-back launches
-    traffic, traffic_source = load_traffic(F) if args.workload == "nlm" else (None, "not profiled for this workload")
+    fp = loaded_kernel_fingerprint(mid.LIB_PATH, args.workload)
+    traffic, traffic_source = load_traffic(F, fp) if args.workload == "nlm" else (None, "not profiled for this workload")
     res = {
         "metric": metric,
         "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -476,16 +542,17 @@ def main():
                    "parallelism": f"frame-sharded x{world}, no data-path collective",
                    **({"process_group": process_group} if process_group else {})},
         "roofline": {
-            "bound": "valu", "bound_contract_enum": "mfma", "achieved": round(flop_px * px_per_launch / avg_launch_s / 1e12, 3),
+            "bound": "mfma", "bound_actual": "valu", "achieved": round(flop_px * px_per_launch / avg_launch_s / 1e12, 3),
             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop_px * px_per_launch / avg_launch_s / 1e12 / PEAK_FP32_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": kernel, "avg_launch_ms": round(avg_launch_s * 1e3, 4),
             # spread of the K timed launches (hipEvent pairs on the launch stream, one pair per step)
             "kernel_ms_min": round(min(kernel_ms) / launches_per_step, 4), "kernel_ms_max": round(max(kernel_ms) / launches_per_step, 4),
-            **load_utilisation(args.workload),
-            "note": "compute roofline: the kernel is bound by fp32 vector (VALU) issue and contains no MFMA instruction, so `bound` says "
-                    "\"valu\"; the contract's two-valued enum would file it under its compute entry (`bound_contract_enum`). The peak is "
+            "kernel_code_sha256": fp[0],
+            **load_utilisation(args.workload, fp),
+            "note": "compute roofline: `bound` is the contract's two-valued enum (hbm | mfma) and this kernel belongs on its compute side; "
+                    "`bound_actual` says what binds it in fact -- fp32 vector (VALU) issue: the kernel contains no MFMA instruction. The peak is "
                     "the fp32 vector peak, which equals the dense f32 MFMA peak on gfx950 (157.3 TFLOP/s). Algorithmic "
                     f"flops = {flop_note} x px per launch.",
             "hbm": {"achieved_GBs": round(bytes_px * px_per_launch / avg_launch_s / 1e9, 1),
@@ -540,7 +607,7 @@ def main():
         # complete (the timed region and its max-over-ranks reduction finished on every rank before any extra started),
         # `also.error` names the extra that was in flight, and the exit code says that this run did not end cleanly.
         os._exit(3)
-    watchdog_s = float(os.environ.get("MID_BENCH_WATCHDOG_S", "300"))      # (tests shorten it; see MID_BENCH_TEST_HANG below)
+    watchdog_s = float(WATCHDOG_S)
     watchdog = threading.Timer(watchdog_s, on_timeout)
     watchdog.daemon = True
     watchdog.start()
@@ -548,8 +615,6 @@ def main():
     def guarded(name, fn):
         in_flight["extra"] = name
         try:
-            if os.environ.get("MID_BENCH_TEST_HANG") == name:       # tests/test_gpu_rccl_one_rank.py: an extra that never returns
-                time.sleep(3600)
             fn()
         except Exception as e:          # an extra must never take the measurement down with it
             also[name + "_error"] = f"{type(e).__name__}: {e}"
@@ -744,7 +809,14 @@ def main():
                 barrier()
                 te = (time.perf_counter() - t1) / reps
                 recv, sent, xms = comm.last_exchange()
-            per_rank = [te, float(recv), float(sent), float(xms), 1.0 if same else 0.0]
+                tl = comm.last_timeline()                       # device timeline of the LAST timed repetition
+                order = comm.last_issue_order()
+                rc_n, rc_rank, rc_ver = comm.rccl_info()        # what RCCL itself reports for this communicator
+                prio = comm.stream_priority()
+            hidden = tl["halo_hidden_frac"]
+            per_rank = [te, float(recv), float(sent), float(xms), 1.0 if same else 0.0,
+                        tl["exchange_start_ms"], tl["exchange_end_ms"], tl["interior_end_ms"], tl["end_ms"],
+                        -1.0 if hidden is None else float(hidden), float(rc_n), float(rc_rank)]
             if world > 1:
                 t = torch.tensor(per_rank, device=coll_device, dtype=torch.float64)
                 allr = [torch.empty_like(t) for _ in range(world)]
@@ -753,14 +825,41 @@ def main():
             else:
                 rows = [per_rank]
             te = max(r[0] for r in rows)
-            also["temporal_nlm_k2_native"] = {"Mpixel/s_out": round(n_seq * NPIX / 1e6 / te, 1), "frames": n_seq,
-                                              "ms_per_sequence": round(te * 1e3, 3),
-                                              "halo_bytes_recv_per_rank": [int(r[1]) for r in rows],
-                                              "halo_bytes_sent_per_rank": [int(r[2]) for r in rows],
-                                              "exchange_ms_per_rank": [round(r[3], 4) for r in rows],
-                                              "bit_identical_to_single_launch_per_rank": [bool(r[4]) for r in rows],
-                                              "path": "C++: mid_comm_create (ncclCommInitRank via dlopen) + mid_nlm_temporal_sharded "
-                                                      "(ncclSend/ncclRecv in one group on the exchange stream, interior launches meanwhile)"}
+            nat = {"Mpixel/s_out": round(n_seq * NPIX / 1e6 / te, 1), "frames": n_seq,
+                   "ms_per_sequence": round(te * 1e3, 3),
+                   "halo_bytes_recv_per_rank": [int(r[1]) for r in rows],
+                   "halo_bytes_sent_per_rank": [int(r[2]) for r in rows],
+                   "exchange_ms_per_rank": [round(r[3], 4) for r in rows],
+                   "bit_identical_to_single_launch_per_rank": [bool(r[4]) for r in rows],
+                   # device timeline of one call, ms from the call's first event on the launch stream, per rank
+                   "timeline_ms_per_rank": [{"exchange_start": round(r[5], 4), "exchange_end": round(r[6], 4),
+                                             "interior_end": round(r[7], 4), "end": round(r[8], 4)} for r in rows],
+                   "halo_hidden_frac_per_rank": [None if r[9] < 0 else round(r[9], 4) for r in rows],
+                   "issue_order_rank0": order, "exchange_stream_priority": {"priority": prio[0], "least": prio[1], "greatest": prio[2]},
+                   "rccl": {"comm_count_per_rank": [int(r[10]) for r in rows], "user_rank_per_rank": [int(r[11]) for r in rows], "version": rc_ver},
+                   "path": "C++: mid_comm_create (ncclCommInitRank via dlopen) + mid_nlm_temporal_sharded "
+                           "(ncclSend/ncclRecv in one group on the highest-priority exchange stream, interior launches meanwhile)"}
+            also["temporal_nlm_k2_native"] = nat
+            # The sharded path at the top level of the line (the headline above is replicas: weak scaling of independent batches):
+            # BASELINE configs[4] -- ONE 64-frame 1080p sequence, temporal +-2 -- split over the ranks; the same job at every N.
+            hid = [x for x in nat["halo_hidden_frac_per_rank"] if x is not None]
+            res["scaling_strong"] = {
+                "workload": "nlm_temporal_k2_64_frames_1080p_hdr (BASELINE configs[4]): one sequence, contiguous frame blocks per rank, halo over RCCL",
+                "metric": "output Mpixel/s (64 x 1920 x 1080 / max-over-ranks seconds per sequence)",
+                "value": nat["Mpixel/s_out"], "unit": "Mpixel/s", "n_gpus": world, "scaling": "strong", "ms_per_sequence": nat["ms_per_sequence"],
+                "frames_per_rank": [c for _, c in sharding.partition(n_seq, world)],
+                "bit_identical_to_single_launch_per_rank": nat["bit_identical_to_single_launch_per_rank"],
+                "bytes_on_the_wire": int(sum(nat["halo_bytes_sent_per_rank"])),
+                "rccl_comm_count": nat["rccl"]["comm_count_per_rank"], "rccl_version": rc_ver,
+                "exchange_ms_per_rank": nat["exchange_ms_per_rank"],
+                "halo_hidden_frac": (round(min(hid), 4) if hid else None),
+                "halo_hidden_frac_per_rank": nat["halo_hidden_frac_per_rank"],
+                "halo_hidden_frac_def": "share of a rank's exchange (first receive posted .. last transfer complete, device timeline) that ran while "
+                                        "its interior launches were still executing: (min(exchange_end, interior_end) - exchange_start) / "
+                                        "(exchange_end - exchange_start); the value is the worst rank's; null with one rank (nothing is exchanged)",
+                "hardware_status": ("measured in this run" if world > 1 and not rehearse else
+                                    "one rank: no exchange took place -- the N >= 2 figures are unmeasured on hardware until a multi-GPU run"),
+            }
 
         guarded("temporal_native", extra_temporal_native)
 

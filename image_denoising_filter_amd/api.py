@@ -500,3 +500,9 @@ class Comm:
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _check(lib.mid_comm_stream_priority(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "mid_comm_stream_priority")
         return a.value, b.value, c.value
+
+    def rccl_info(self):
+        """(ncclCommCount, ncclCommUserRank, ncclGetVersion) as RCCL reports them; -1 where the loaded library lacks the call."""
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(lib.mid_comm_rccl_info(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "mid_comm_rccl_info")
+        return a.value, b.value, c.value

@@ -50,6 +50,10 @@ struct Rccl {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    // optional (reporting only; the test stand-in does not have them)
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     std::string why;
 };
 
@@ -80,6 +84,9 @@ Rccl &rccl()
         x.Send = (decltype(x.Send))sym("ncclSend");
         x.Recv = (decltype(x.Recv))sym("ncclRecv");
         x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
+        x.CommCount = (decltype(x.CommCount))dlsym(x.so, "ncclCommCount");
+        x.CommUserRank = (decltype(x.CommUserRank))dlsym(x.so, "ncclCommUserRank");
+        x.GetVersion = (decltype(x.GetVersion))dlsym(x.so, "ncclGetVersion");
         return x;
     }();
     return r;
@@ -546,5 +553,22 @@ extern "C" int mid_comm_stream_priority(mid_comm *c, int *priority, int *least, 
     if (priority) *priority = pr;
     if (least) *least = lo;
     if (greatest) *greatest = hi;
+    return MID_OK;
+}
+
+// What RCCL ITSELF says about this communicator (ncclCommCount / ncclCommUserRank / ncclGetVersion) -- as opposed to
+// mid_comm_rank, which returns what the caller passed to mid_comm_create.  -1 where the loaded library lacks the call.
+extern "C" int mid_comm_rccl_info(mid_comm *c, int *nranks, int *user_rank, int *version)
+{
+    MID_REQUIRE(c != nullptr, "comm_rccl_info: comm is NULL");
+    MID_REQUIRE(!c->aborted, "comm_rccl_info: the communicator was aborted");
+    if (int rc = need_rccl()) return rc;
+    int n = -1, r = -1, v = -1;
+    if (rccl().CommCount) MID_NCCL(rccl().CommCount(c->comm, &n));
+    if (rccl().CommUserRank) MID_NCCL(rccl().CommUserRank(c->comm, &r));
+    if (rccl().GetVersion) MID_NCCL(rccl().GetVersion(&v));
+    if (nranks) *nranks = n;
+    if (user_rank) *user_rank = r;
+    if (version) *version = v;
     return MID_OK;
 }

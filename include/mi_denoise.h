@@ -291,6 +291,8 @@ int mid_comm_last_exchange(mid_comm *comm, size_t *bytes_recv, size_t *bytes_sen
 int mid_comm_last_timeline(mid_comm *comm, float t_ms[4]);
 int mid_comm_last_issue_order(mid_comm *comm, char *buf, size_t buflen);
 int mid_comm_stream_priority(mid_comm *comm, int *priority, int *least, int *greatest);
+/* What RCCL itself reports for the communicator: ncclCommCount, ncclCommUserRank, ncclGetVersion (-1 where unavailable). */
+int mid_comm_rccl_info(mid_comm *comm, int *nranks, int *user_rank, int *version);
 
 /* ---- 8f-2: image files ------------------------------------------------------------------
  * mid_image_load = LoadImages (src/main.cpp:145-229): ".exr" -> RGBA32F (tinyexr LoadEXR: missing

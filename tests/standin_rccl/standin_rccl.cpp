@@ -13,6 +13,9 @@
 // What it is NOT: a transport.  It proves the library's plans, buffer bookkeeping, stream/event plumbing and failure handling with
 // N > 1 ranks on real kernels; xGMI, RCCL's own kernels and multi-process rendezvous stay unexercised until a multi-GPU run.
 // STANDIN_RCCL_FAIL_SEND_RANK=<r>: ncclSend fails on rank r (failure-path tests).
+// STANDIN_RCCL_DELAY_MS=<ms>: every receive is held back by a one-wave kernel that spins for about that long on the receiver's
+// exchange stream before the copy -- a slow wire, so that a test can see on the device timeline that interior launches do not
+// wait for the halo and boundary launches do (the kernel reads the 100 MHz wall clock and always terminates).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <condition_variable>
@@ -25,6 +28,19 @@
 #include <vector>
 
 namespace {
+
+__global__ void standin_hold(long long ticks)      // wall_clock64: constant 100 MHz on gfx950
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+long long delay_ticks()
+{
+    const char *e = getenv("STANDIN_RCCL_DELAY_MS");
+    const double ms = e && *e ? atof(e) : 0.0;
+    return ms > 0 && ms <= 2000 ? (long long)(ms * 1e5) : 0;          // capped at 2 s: a test knob, not a hang
+}
 
 struct Posted {                 // one posted send, waiting for (or matched with) its receive
     const void *src;
@@ -104,6 +120,10 @@ ncclResult_t flush()
         if (p->bytes != op.bytes) return ncclInvalidArgument;
         if (hipSetDevice(c->device) != hipSuccess) return ncclUnhandledCudaError;
         if (hipStreamWaitEvent(op.stream, p->ready, 0) != hipSuccess) return ncclUnhandledCudaError;
+        if (const long long ticks = delay_ticks()) {
+            standin_hold<<<1, 64, 0, op.stream>>>(ticks);
+            if (hipGetLastError() != hipSuccess) return ncclUnhandledCudaError;
+        }
         if (hipMemcpyAsync(op.buf, p->src, op.bytes, hipMemcpyDeviceToDevice, op.stream) != hipSuccess) return ncclUnhandledCudaError;
         hipEvent_t done;
         if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;

@@ -51,11 +51,26 @@ def test_bench_spawns_its_own_ranks(n):
     assert d["dry_run"] is True and d["n_gpus"] == n
 
 
-def test_bench_launcher_reports_a_failed_rank():
-    """A rank that dies makes the launcher stop the others and return non-zero -- never a 1-GPU number."""
+def test_bench_launcher_reports_a_failed_rank(tmp_path):
+    """A rank that dies makes the launcher stop the others and return non-zero -- never a 1-GPU number.  bench.py has no
+    failure hook of its own: the launcher is driven through a wrapper script whose rank 1 exits (code 7) the moment the
+    rehearsal builds its stand-in context, i.e. after the process group is up and before the first barrier."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env["MID_BENCH_TEST_FAIL_RANK"] = "1"
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "4", "--dry-run"]
+    wrapper = tmp_path / "bench.py"
+    wrapper.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import importlib.util\n"
+        f"spec = importlib.util.spec_from_file_location('bench_under_test', {os.path.join(ROOT, 'bench.py')!r})\n"
+        "bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)\n"
+        "bench.__file__ = os.path.abspath(__file__)          # launch_ranks() re-starts THIS script for every rank\n"
+        "def die(self):\n"
+        "    if os.environ.get('RANK') == '1':\n"
+        "        os._exit(7)\n"
+        "    self.launches = []\n"
+        "bench._DryContext.__init__ = die\n"
+        "bench.main()\n")
+    cmd = [sys.executable, str(wrapper), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "4", "--dry-run"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -141,6 +141,20 @@ def test_bench_stdout_is_exactly_one_json_line_with_the_native_rccl_extra(tmp_pa
     assert nat["bit_identical_to_single_launch_per_rank"] == [True] and nat["halo_bytes_recv_per_rank"] == [0]
     assert not [k for k in d["also"] if k.endswith("_error")], d["also"]
     assert d["also"]["bilateral_r8_texture_over_linear"] > 0
+    # the sharded path at the top level of the line: configs[4] through the C++ RCCL path, with what the
+    # communicator itself reports; one rank here, so nothing was exchanged and the line says so
+    ss = d["scaling_strong"]
+    assert ss["n_gpus"] == 1 and ss["scaling"] == "strong" and ss["value"] == nat["Mpixel/s_out"] > 0
+    assert ss["bit_identical_to_single_launch_per_rank"] == [True] and ss["bytes_on_the_wire"] == 0
+    assert ss["rccl_comm_count"] == [1] and ss["rccl_version"] > 0 and ss["halo_hidden_frac"] is None
+    assert "unmeasured on hardware" in ss["hardware_status"]
+    assert nat["issue_order_rank0"].startswith("I") and "X" not in nat["issue_order_rank0"]
+    pr = nat["exchange_stream_priority"]
+    assert pr["priority"] == pr["greatest"] <= pr["least"]
+    assert nat["timeline_ms_per_rank"][0]["end"] > 0 and nat["timeline_ms_per_rank"][0]["exchange_end"] == 0
+    # the contract's two-valued enum, with the truthful value beside it
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["bound_actual"] == "valu"
+    assert len(d["roofline"]["kernel_code_sha256"]) == 64
 
 
 def test_bench_watchdog_prints_the_headline_names_the_hung_extra_and_exits_nonzero(tmp_path):
@@ -148,9 +162,19 @@ def test_bench_watchdog_prints_the_headline_names_the_hung_extra_and_exits_nonze
     prints the complete headline line with `also.error` naming the extra in flight and ends the process with exit code 3 --
     for every world size (a process abandoned in the middle of GPU work must not report success)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(MID_BENCH_WATCHDOG_S="25", MID_BENCH_TEST_HANG="bilateral_batch")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "2", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    # bench.py carries no test hook: this wrapper imports it, shortens its watchdog and makes the one library call that only the
+    # `bilateral_batch` extra uses (mid_bilateral_batch through Context.bilateral_batch_dev) never return
+    wrapper = tmp_path / "bench_with_a_hung_extra.py"
+    wrapper.write_text(
+        "import sys, time\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "import image_denoising_filter_amd as mid\n"
+        "bench.WATCHDOG_S = 25\n"
+        "mid.Context.bilateral_batch_dev = lambda *a, **k: time.sleep(3600)\n"
+        "sys.argv = ['bench.py', '--steps', '2', '--warmup', '1', '--frames', '2', '--no-cpu-baseline']\n"
+        "bench.main()\n")
+    r = subprocess.run([sys.executable, str(wrapper)], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

@@ -139,3 +139,84 @@ def test_cli_a_rank_that_fails_inside_the_exchange_ends_the_run_with_an_error_no
                         "--gpus", "3", "--share-device"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0, r.stdout
     assert "halo exchange" in r.stdout + r.stderr
+
+
+_TIMELINE_WORKER = r'''
+import json, re, sys, threading
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import image_denoising_filter_amd as mid
+
+CFG = dict(search=(-10, 11), patch=(-3, 4))
+world, n, k, h, w = 2, 16, 2, 270, 480
+rng = np.random.default_rng(1)
+seq = [(rng.random((h, w, 4), dtype=np.float32) * 0.8).astype(np.float32) for _ in range(n)]
+whole = mid.Context(0).nlm_temporal(seq, k=k, **CFG)
+ctxs = [mid.Context(0) for _ in range(world)]
+comms = mid.comm_create_all(ctxs)
+rep, errs = {}, []
+
+def rank_main(r):
+    try:
+        c, comm = ctxs[r], comms[r]
+        start, count = mid.shard_block(n, world, r)
+        d_in = [c.upload(seq[start + i]) for i in range(count)]
+        d_out = [c.alloc(h * w * 16) for _ in range(count)]
+        comm.reserve(h * w * 16, k)
+        comm.nlm_temporal_sharded_dev([d.ptr for d in d_in], [d.ptr for d in d_out], w, h, n, k, 0.5, CFG["search"], CFG["patch"], mid.FMT_RGBA32F)
+        order = comm.last_issue_order()            # host-side: available the moment the call returns, nothing has to finish
+        tl = comm.last_timeline()                  # waits for the call
+        for i in range(count):
+            assert np.array_equal(c.download(d_out[i], (h, w, 4), np.float32), whole[start + i]), (r, i)
+        rep[str(r)] = {"order": order, "timeline": tl, "priority": comm.stream_priority(), "exchange_ms": comm.last_exchange()[2]}
+    except Exception as e:  # noqa: BLE001
+        errs.append(f"rank {r}: {e!r}")
+
+th = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+for t in th: t.start()
+for t in th: t.join(timeout=120)
+assert not any(t.is_alive() for t in th), "a rank hangs"
+assert not errs, errs
+for cm in comms: cm.close()
+# one rank: nothing to exchange, no wait
+ctx1 = mid.Context(0)
+with mid.Comm(ctx1, mid.comm_unique_id(), 0, 1) as c1:
+    d_in = [ctx1.upload(f) for f in seq[:5]]
+    d_out = [ctx1.alloc(h * w * 16) for _ in range(5)]
+    c1.nlm_temporal_sharded_dev([d.ptr for d in d_in], [d.ptr for d in d_out], w, h, 5, k, 0.5, CFG["search"], CFG["patch"], mid.FMT_RGBA32F)
+    rep["solo"] = {"order": c1.last_issue_order(), "timeline": c1.last_timeline()}
+print("TIMELINE " + json.dumps(rep), flush=True)
+'''
+
+
+def test_interior_launches_are_issued_before_the_wait_for_the_halo_and_do_not_wait_for_it(tmp_path):
+    """VERDICT r4 item 2(d): the overlap of halo exchange and interior compute is STRUCTURAL.  Host side: every rank issues the
+    exchange group, then all its interior launches, and only then tells its stream to wait for the exchange ('X', 'I'..., 'W',
+    'B'...: mid_comm_last_issue_order).  Device side, with the stand-in's wire slowed to 30 ms per received frame
+    (STANDIN_RCCL_DELAY_MS): the interior launches END while the exchange is still in flight, the call ends after it
+    (the boundary launches did wait), the measured exchange lasts at least the two delays, and halo_hidden_frac -- the number
+    the first multi-GPU bench will report -- is the share of the exchange the interior launches covered.  The exchange
+    stream carries the device's highest priority."""
+    import re
+    script = tmp_path / "worker.py"
+    script.write_text(_TIMELINE_WORKER)
+    r = subprocess.run([sys.executable, str(script), ROOT], env=dict(_env(), STANDIN_RCCL_DELAY_MS="30"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("TIMELINE ")][0][9:])
+    for rank in ("0", "1"):
+        x = rep[rank]
+        assert re.fullmatch(r"XI+WB+", x["order"]), x["order"]
+        t = x["timeline"]
+        assert 0 <= t["exchange_start_ms"] < t["exchange_end_ms"]
+        assert t["exchange_end_ms"] - t["exchange_start_ms"] >= 55.0, t                      # two held-back receives of 30 ms
+        assert abs((t["exchange_end_ms"] - t["exchange_start_ms"]) - x["exchange_ms"]) < 0.5
+        assert 0 < t["interior_end_ms"] < t["exchange_end_ms"], t                            # the interior did not wait for the halo
+        assert t["end_ms"] > t["exchange_end_ms"], t                                         # the boundary outputs did
+        assert t["halo_hidden_frac"] is not None and 0.0 < t["halo_hidden_frac"] < 1.0
+        want = (min(t["exchange_end_ms"], t["interior_end_ms"]) - t["exchange_start_ms"]) / (t["exchange_end_ms"] - t["exchange_start_ms"])
+        assert abs(t["halo_hidden_frac"] - max(0.0, want)) < 1e-6
+        pr, least, greatest = x["priority"]
+        assert pr == greatest and greatest <= least, x["priority"]
+    solo = rep["solo"]
+    assert re.fullmatch(r"I+B*", solo["order"]) and "X" not in solo["order"] and "W" not in solo["order"], solo["order"]
+    assert solo["timeline"]["halo_hidden_frac"] is None and solo["timeline"]["end_ms"] > 0

@@ -66,7 +66,9 @@ with mid.Comm(ctx, uid, 0, 1) as comm:
     big_out = [ctx.alloc(frame.nbytes) for _ in range(nb)]
     args = ([d.ptr for d in big_in], [d.ptr for d in big_out], wb, hb, nb, 2, 0.5, (-10, 11), (-3, 4), mid.FMT_RGBA32F)
     comm.reserve(frame.nbytes, 2)
-    comm.nlm_temporal_sharded_dev(*args, stream=sA.cuda_stream)          # 34 frame pairs at ~0.45 ms: still running ...
+    with torch.cuda.stream(sA):
+        torch.cuda._sleep(100_000_000)                                   # stream A is busy for 40 ms (shader clock) to 1 s (100 MHz counter),
+    comm.nlm_temporal_sharded_dev(*args, stream=sA.cuda_stream)          # so this call is deterministically still in flight ...
     try:
         comm.nlm_temporal_sharded_dev(*args, stream=sB.cuda_stream)      # ... when this one arrives on the other stream
         raise SystemExit("a second stream was accepted while the first call was in flight")

@@ -9,6 +9,9 @@ TAG=${1:-r01}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# sha256 of the bench kernel's code in the library that is about to be profiled: bench.py compares it with the library it
+# loads before it reads these counters back (image_denoising_filter_amd/_codeobj.py; pure Python, no GPU)
+python3 $R/image_denoising_filter_amd/_codeobj.py $R/image_denoising_filter_amd/libmi_denoise.so > $OUT/code_fingerprint.json || { echo "fingerprint failed"; exit 1; }
 BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 [ "$2" = "trace_main_only" ] || rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
 BENCH2="$BENCH --no-extras"

@@ -99,6 +99,14 @@ for key, d in pmc.items():
     out[f"{key[0]} grid={key[1]}"] = {c: {"launches": len(v), "avg_per_launch": sum(v) / len(v)} for c, v in sorted(d.items())}
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 
+# ---- fingerprint of the profiled bench kernel (tools/run_profiles.sh writes it ON THE GPU BOX from the library it profiled) ----
+FP = None
+fp_path = os.path.join(src, "code_fingerprint.json")
+if os.path.exists(fp_path):
+    FP = json.load(open(fp_path))
+else:
+    print("WARNING: no code_fingerprint.json next to the counters: bench.py will refuse to read these figures back")
+
 # ---- traffic of the dominant kernel (the 8-frame bench launches = the largest grid) ----------
 dom = [k for k in pmc if "nlm_strip_kernel" in k[0]]
 if dom:
@@ -114,6 +122,7 @@ if dom:
                            "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact for 16-B/lane streaming stores",
              "algorithmic_bytes_per_launch": int(k[1]) // 256 // (34 * 34) * 1920 * 1080 * 32,
              "date": __import__("time").strftime("%Y-%m-%d", __import__("time").gmtime()),
+             **({"kernel_symbol": FP["kernel_symbol"], "kernel_code_sha256": FP["kernel_code_sha256"]} if FP else {}),
              "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"}
         json.dump(t, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
         print(json.dumps(t, indent=1))
@@ -253,6 +262,8 @@ for name, key, cls in (("nlm_bench", pick("nlm_strip_kernel<-10, 11, -3, 4, 8, 4
         u = utilisation(key, cls, OFFSETS.get(name))
         if u:
             util["kernels"][name] = u
+if FP:
+    util["bench_kernel_symbol"], util["bench_kernel_code_sha256"] = FP["kernel_symbol"], FP["kernel_code_sha256"]
 if util["kernels"]:
     json.dump(util, open(os.path.join(dst, f"{tag}_utilisation.json"), "w"), indent=1)
     for n_, u in util["kernels"].items():

@@ -104,6 +104,15 @@ static void cpu_bilateral_refpath(const std::vector<Pixel> &in, int w, int h, in
     }
 }
 
+// A named ROCTx range (mid_range_push/pop): shows up in `rocprofv3 --marker-trace`, does nothing otherwise.  The reference
+// brackets the same stages with timestamp queries (src/main.cpp:793-796,812-814,842-844).
+struct TraceRange {
+    explicit TraceRange(const std::string &name) { (void)mid_range_push(name.c_str()); }
+    ~TraceRange() { (void)mid_range_pop(); }
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+};
+
 class DenoiseApplication {
     Options opt;
     double m_execMs = 0, m_transferMs = 0;
@@ -181,6 +190,8 @@ public:
     void RunOnGPU(bool nlmFilter, bool nonlinear, bool multiframe, bool execAndCopyOverlap, bool useLayers)
     {
         const bool linear = !nonlinear;                                              // :1311
+        TraceRange mode_range(std::string("RunOnGPU ") + (linear ? "linear" : "nonlinear") + (nlmFilter ? " nlm" : " bialteral") +
+                              (multiframe ? " multiframe" : "") + (execAndCopyOverlap ? " overlap" : "") + (useLayers ? " layers" : ""));
         if (!(nlmFilter || !multiframe)) throw std::runtime_error("multiframe works only with nlm");        // assert :1315
         if (!(multiframe || !execAndCopyOverlap)) throw std::runtime_error("overlap needs multiframe");     // assert :1316
         if (linear && (nlmFilter || useLayers)) throw std::runtime_error("nlm/layers exist for the texture path only");
@@ -196,7 +207,7 @@ public:
         const bool hdr = is_hdr(opt.image);
         mid_ctx *pin = opt.pageable_host ? nullptr : ctx;              // where decoded images live
         if (opt.pageable_host) std::cout << "\thost buffers: pageable (bounced inside the library)\n";
-        HostImage target = load(opt.image, false, pin);
+        HostImage target = [&] { TraceRange r("decode target"); return load(opt.image, false, pin); }();
         const int w = target.w, h = target.h;
         const size_t npix = (size_t)w * h, out_bytes = npix * sizeof(Pixel);
         const int fmt = target.format;
@@ -257,7 +268,8 @@ public:
             void *dIn = nullptr, *dOut = nullptr;
             MID_CHECK(mid_alloc(ctx, target.size(), &dIn));
             MID_CHECK(mid_alloc(ctx, out_bytes, &dOut));
-            timed(m_transferMs, [&] { MID_CHECK(mid_memcpy_h2d(ctx, dIn, target.data(), target.size(), nullptr)); });
+            { TraceRange r("upload target"); timed(m_transferMs, [&] { MID_CHECK(mid_memcpy_h2d(ctx, dIn, target.data(), target.size(), nullptr)); }); }
+            TraceRange dispatch_range("dispatch");
             if (nlmFilter) {                                                                    // single-frame NLM, :1577-1606 with one frame
                 mid_nlm_params p{w, h, opt.nlm_h, opt.search_lo, opt.search_hi, opt.patch_lo, opt.patch_hi, fmt};
                 const void *fr[1] = {dIn};
@@ -285,6 +297,8 @@ public:
                 timed(m_execMs, [&] { MID_CHECK(mid_bilateral(ctx, &p, dIn, (mid_pixel *)dOut, nullptr)); });
             }
             std::cout << "\tgetting image back\n";
+            (void)mid_range_pop();                                                              // "dispatch" ends, "download" begins
+            (void)mid_range_push("download");
             timed(m_transferMs, [&] { MID_CHECK(mid_memcpy_d2h(ctx, result.data(), dOut, out_bytes, nullptr)); });
             MID_CHECK(mid_stream_sync(ctx, nullptr));
             mid_free(ctx, dIn); mid_free(ctx, dOut);
@@ -296,7 +310,7 @@ public:
         outputFileName += multiframe ? "-multiframe" : "";
         outputFileName += execAndCopyOverlap ? "-overlap" : "";
         outputFileName += useLayers ? "-layers" : "";
-        save(outputFileName, result.data(), w, h, hdr);
+        { TraceRange r("encode + write " + outputFileName); save(outputFileName, result.data(), w, h, hdr); }
         std::cout << "\tcleaning up\n";
     }
 

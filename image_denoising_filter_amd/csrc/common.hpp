@@ -92,6 +92,18 @@ void bounce_release(mid_ctx *ctx);     // waits for the last chunks and frees bo
 int nlm_temporal_out(mid_ctx *ctx, const mid_nlm_params *p, const void *const *frames, int n_frames, int k,
                      int first, int count, void *const *out, int out_u8, void *stream, int corunning = 0);
 
+// ROCTx ranges (csrc/markers.cpp): no-ops unless the process already holds a ROCTx (rocprofv3 --marker-trace preloads one).
+bool markers_active();
+void range_push(const char *name);
+void range_pop();
+struct Range {
+    bool on;
+    explicit Range(const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+    ~Range();
+    Range(const Range &) = delete;
+    Range &operator=(const Range &) = delete;
+};
+
 // Raise the dynamic-LDS limit of `kern` once per context (kernels here use up to 160 KB).
 inline int ensure_lds(mid_ctx *ctx, const void *kern, size_t bytes)
 {

@@ -113,6 +113,7 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
     // and the events live in the context and are only allocated when a call needs more or larger ones than any call before
     // it (the first call of a context, a larger frame size, a wider window): in a steady stream of sequences nothing is.
     const auto wall0 = std::chrono::steady_clock::now();
+    Range call_range("mid_sequence_nlm frames=%d k=%d outputs=[%d,%d)%s", n, k, first, first + count, out_u8 ? " u8" : "");
     std::lock_guard<std::mutex> pipe_lock(ctx->pipe.mu);
     DrainOnExit drain{ctx};
     mid_pipe_set &dring = ctx->pipe.ring, &dout = ctx->pipe.out;
@@ -124,6 +125,7 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
 
     int next_upload = f_lo;
     auto upload = [&](int f) -> int {
+        Range r("upload %d", f);
         if (f - f_lo >= ring) {   // the slot still holds frame f-ring, read by outputs (f-ring)-k .. (f-ring)+k
             int last_reader = f - ring + k;
             if (last_reader > first + count - 1) last_reader = first + count - 1;
@@ -150,6 +152,7 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
     for (int i = 0; i < count; ++i) out_pinned = out_pinned && host_is_pinned(host_out[i], dl_bytes);
     auto download = [&](int bi) -> int {
         const int b0 = first + bi * B, bn = (first + count - b0) < B ? (first + count - b0) : B;
+        Range r("download %d", b0);
         MID_HIP(hipStreamWaitEvent(ctx->download, c1.ev[bi], 0));
         MID_HIP(hipEventRecord(d0.ev[bi], ctx->download));
         for (int i = 0; i < bn; ++i)
@@ -182,11 +185,14 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
         for (int f = lo; f <= need; ++f) tbl[f - lo] = slot(f);
         mid_pixel *o[kMaxFrames];
         for (int i = 0; i < bn; ++i) o[i] = (mid_pixel *)dout.p[(bi % DEPTH) * B + i];
-        MID_HIP(hipEventRecord(c0.ev[bi], cs));
-        // out_u8: GetImageFromGPU's u8 conversion (src/main.cpp:97-103) in the kernel's epilogue -- a quarter of the
-        // bytes to write and to download
-        if (int rc = nlm_temporal_out(ctx, p, tbl, need - lo + 1, k, b0 - lo, bn, (void *const *)o, out_u8 ? 1 : 0, cs, 1)) return rc;
-        MID_HIP(hipEventRecord(c1.ev[bi], cs));
+        {
+            Range nlm_range("nlm %d", b0);
+            MID_HIP(hipEventRecord(c0.ev[bi], cs));
+            // out_u8: GetImageFromGPU's u8 conversion (src/main.cpp:97-103) in the kernel's epilogue -- a quarter of the
+            // bytes to write and to download
+            if (int rc = nlm_temporal_out(ctx, p, tbl, need - lo + 1, k, b0 - lo, bn, (void *const *)o, out_u8 ? 1 : 0, cs, 1)) return rc;
+            MID_HIP(hipEventRecord(c1.ev[bi], cs));
+        }
 
         while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }
 
@@ -200,10 +206,13 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
         }
     }
     if (!out_pinned && overlap) { if (int rc = download(nb - 1)) return rc; }
-    MID_HIP(hipStreamSynchronize(ctx->upload));
-    MID_HIP(hipStreamSynchronize(ctx->compute));
-    MID_HIP(hipStreamSynchronize(ctx->compute2));
-    MID_HIP(hipStreamSynchronize(ctx->download));
+    {
+        Range r("drain");
+        MID_HIP(hipStreamSynchronize(ctx->upload));
+        MID_HIP(hipStreamSynchronize(ctx->compute));
+        MID_HIP(hipStreamSynchronize(ctx->compute2));
+        MID_HIP(hipStreamSynchronize(ctx->download));
+    }
     const auto wall1 = std::chrono::steady_clock::now();
 
     if (timings_ms) {
@@ -255,6 +264,7 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
 
     // (clock and cached buffers as in sequence_impl: timings_ms[0] covers the whole call)
     const auto wall0 = std::chrono::steady_clock::now();
+    Range call_range("mid_nlm_multiframe frames=%d overlap=%d", n, overlap);
     std::lock_guard<std::mutex> pipe_lock(ctx->pipe.mu);
     DrainOnExit drain{ctx};
     mid_pipe_set &dtarget = ctx->pipe.target, &dslot = ctx->pipe.slots, &dW = ctx->pipe.weights, &dout = ctx->pipe.result;
@@ -274,6 +284,7 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
     MID_HIP(hipStreamWaitEvent(ctx->compute, misc.ev[1], 0));
 
     auto upload = [&](int f) -> int {
+        Range r("upload %d", f);
         if (f >= SLOTS) MID_HIP(hipStreamWaitEvent(ctx->upload, c1.ev[f - SLOTS], 0));   // slot still read by dispatch f-SLOTS
         MID_HIP(hipEventRecord(up0.ev[f], ctx->upload));
         if (int rc = copy_h2d(ctx, dslot.p[f % SLOTS], host_frames[f], in_bytes, ctx->upload)) return rc;
@@ -285,6 +296,7 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
         // overlap: frames f+1, f+2 ride beside dispatch f (their slots were last read by dispatches already enqueued)
         const int ahead = overlap ? (f + SLOTS - 1 < n - 1 ? f + SLOTS - 1 : n - 1) : f;
         while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }
+        Range r("nlm %d", f);
         MID_HIP(hipStreamWaitEvent(ctx->compute, up1.ev[f], 0));
         MID_HIP(hipEventRecord(c0.ev[f], ctx->compute));
         if (int rc = mid_nlm_accum(ctx, p, dtarget.p[0], dslot.p[f % SLOTS], (mid_weightinfo *)dW.p[0], ctx->compute)) return rc;

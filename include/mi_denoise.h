@@ -325,6 +325,14 @@ int mid_timer_tick(mid_timer *t, void *stream);
 int mid_timer_tock(mid_timer *t, void *stream);
 int mid_timer_ms(mid_timer *t, float *ms);
 
+/* Named host ranges for a trace (ROCTx; `rocprofv3 --marker-trace`): the counterpart, for a profiler's timeline, of the
+ * timestamp pairs the reference writes around every submit (src/main.cpp:793-796,812-814,842-844).  The frame pipeline
+ * emits "upload f" / "nlm t" / "download t" inside one range per call; callers bracket their own stages with these two.
+ * Bound to whatever ROCTx the process has ALREADY loaded (rocprofv3 preloads one); nothing is loaded otherwise and the
+ * calls do nothing.  Return 1 when a ROCTx is present, 0 when not. */
+int mid_range_push(const char *name);
+int mid_range_pop(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,7 +105,7 @@ def test_plan_entry_points_under_asan_and_ubsan(tmp_path):
     exe = tmp_path / "shard_plan_sanitize"
     subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-fno-gpu-sanitize", "-fsanitize=address,undefined",
                     "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-O1", "-g", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(csrc, "sharded.cpp"), os.path.join(csrc, "capi.cpp"), os.path.join(csrc, "hostcopy.cpp"), os.path.join(csrc, "pipeline.cpp"),
+                    os.path.join(csrc, "sharded.cpp"), os.path.join(csrc, "capi.cpp"), os.path.join(csrc, "hostcopy.cpp"), os.path.join(csrc, "markers.cpp"), os.path.join(csrc, "pipeline.cpp"),
                     os.path.join(ROOT, "tools", "shard_plan_sanitize.cpp"), "-o", str(exe), "-ldl"], check=True, capture_output=True, timeout=600)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr[-3000:]

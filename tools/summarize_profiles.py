@@ -151,7 +151,7 @@ COST = {"floor": {"plain": 2.0, "dpp": 2.0, "trans": 8.0},
         "bilateral_occupancy": {"plain": 2.22, "dpp": 2.22, "trans": 8.1},
         "same_stream": {"plain": 2.0, "dpp": 4.0, "trans": 8.0}}
 # search offsets per (pixel, neighbour frame) of the NLM kernels that have a fixed count per wave: cycles per wave-offset below
-OFFSETS = {"nlm_bench": 441, "nlm_reference_windows": 196}
+OFFSETS = {"nlm_bench": 441, "nlm_reference_windows": 196, "nlm_temporal_k2": 441 * 5}   # search offsets a wave walks (temporal: x 5 frames per window)
 
 
 def durations_by_kernel():

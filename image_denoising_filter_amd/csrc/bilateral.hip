@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
             if (t < LW * LH) gde_t[t] = make_float4(v.x * a.sc, v.y * a.sc, v.z * a.sc, v.w);
         }
     };
-    if (MODE == 2) prefetch(a.layers[0]);
+    if (MODE == 2 && a.n_layers > 0) prefetch(a.layers[0]);      // (no layers: the loop below does not run, the output is the magenta sentinel)
     // The guide colours (the image itself in MODE 0) are pre-multiplied by sqrt(-kc), so -|dc|^2 is already the
     // colour part of the exp2 argument and the FMA chain can start from the spatial term: 12 ops per tap, not 13.
     fill_tile<FMT, LINEAR>(img_t, LW, LH, in, w, h, X0 - R, Y0 - R, tid, NW * 64, MODE == 0 ? a.sc : 1.0f);

@@ -43,6 +43,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--summarise":
 
 if len(sys.argv) > 2 and sys.argv[1] == "--summarise-stages":
     src, tag = sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "r05")
+    host_src = sys.argv[5] if len(sys.argv) > 5 else None      # a `--marker-trace` ONLY pass: the host-side shares with the least tracer overhead
 
     def newest(pat):
         c = sorted(glob.glob(os.path.join(src, "**", pat), recursive=True), key=os.path.getmtime)
@@ -67,18 +68,29 @@ if len(sys.argv) > 2 and sys.argv[1] == "--summarise-stages":
                 a, b = x, y
         return tot + (b - a if a is not None else 0)
 
+    def host_shares(path):
+        marks = [(col(r, "Function", "Message", "Name"), int(col(r, "Start_Timestamp")), int(col(r, "End_Timestamp"))) for r in csv.DictReader(open(path))]
+        calls = [m for m in marks if m[0].startswith("mid_sequence_nlm")]
+        if not calls:
+            sys.exit("no mid_sequence_nlm range in " + path)
+        name, t0, t1 = calls[-1]                                               # the last (steady-state) pipeline call
+        span = t1 - t0
+        inside = [m for m in marks if m[1] >= t0 and m[2] <= t1 and m is not calls[-1]]
+        host = {"span_ms": round(span / 1e6, 3)}
+        for stage in ("upload", "nlm", "download", "drain"):
+            iv = [(a, b) for n, a, b in inside if n.split()[0] == stage]
+            host[stage] = {"ranges": len(iv), "host_ms": round(sum(b - a for a, b in iv) / 1e6, 3), "share_of_call": round(sum(b - a for a, b in iv) / span, 4)}
+        return name, t0, t1, host
+
     mk = newest("*marker_api_trace.csv")
-    marks = [(col(r, "Function", "Message", "Name"), int(col(r, "Start_Timestamp")), int(col(r, "End_Timestamp"))) for r in csv.DictReader(open(mk))]
-    calls = [m for m in marks if m[0].startswith("mid_sequence_nlm")]
-    if not calls:
-        sys.exit("no mid_sequence_nlm range in " + mk)
-    name, t0, t1 = calls[-1]                                                   # the last (steady-state) pipeline call
+    name, t0, t1, host = host_shares(mk)
     span = t1 - t0
-    inside = [m for m in marks if m[1] >= t0 and m[2] <= t1 and m is not calls[-1]]
-    host = {}
-    for stage in ("upload", "nlm", "download", "drain"):
-        iv = [(a, b) for n, a, b in inside if n.split()[0] == stage]
-        host[stage] = {"ranges": len(iv), "host_ms": round(sum(b - a for a, b in iv) / 1e6, 3), "share_of_call": round(sum(b - a for a, b in iv) / span, 4)}
+    host_source = mk
+    if host_src:
+        c = sorted(glob.glob(os.path.join(host_src, "**", "*marker_api_trace.csv"), recursive=True), key=os.path.getmtime)
+        if c:
+            _, _, _, host = host_shares(c[-1])
+            host_source = c[-1]
     kt = newest("*kernel_trace.csv")
     kern = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(kt))]
     nlm = [(a, b) for a, b, n in kern if "nlm_strip_kernel" in n and a >= t0 and b <= t1]
@@ -104,8 +116,12 @@ if len(sys.argv) > 2 and sys.argv[1] == "--summarise-stages":
                "blit_copy_kernels": {"records": len(blit), "busy_ms": round(union(blit) / 1e6, 3), "share_of_call": round(union(blit) / span, 4)},
                "def": "busy = union of the records' [start, end] intervals inside the call's ROCTx range; memory-copy records are the runtime's SDMA/blit "
                       "copies (direction from the trace), kernels by name"},
-           "host_stage_occupancy": dict(host, **{"def": "time the calling thread spent inside the library's 'upload f' / 'nlm t' / 'download t' / 'drain' ranges "
-                                                        "(issuing work, or -- drain -- waiting for it): the host is not the bottleneck while upload+nlm+download stay far below 1"}),
+           "host_stage_occupancy": dict(host, **{"source": os.path.relpath(host_source, ROOT),
+                                                 "def": "time the calling thread spent inside the library's 'upload f' / 'nlm t' / 'download t' / 'drain' ranges "
+                                                        "(issuing work, or -- drain -- waiting for it), as shares of THIS pass's span_ms; taken from a --marker-trace "
+                                                        "only pass when one is given, because every traced domain slows the issuing thread"}),
+           "tracer_overhead": "the same call takes about 50 ms untraced, 60 ms with --marker-trace alone and 70-95 ms with kernel + memory-copy tracing on top "
+                              "(gpurun_out/prof_r05/pipe_f32_*.log): under a tracer the HOST thread sets the pace, untraced the link does (bench.py pcie_frac 0.95)",
            "sources": [os.path.relpath(x, ROOT) for x in (mk, kt, mc) if x]}
     dst = os.path.join(ROOT, "profiles", f"{tag}_pipeline_occupancy.json")
     json.dump(out, open(dst, "w"), indent=1)

@@ -33,3 +33,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_mix -- $MIX >
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_mix_fetch -- $MIX > $OUT/pmc_mix_fetch.log 2>&1 || { echo "pmc_mix_fetch failed"; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_mix_write -- $MIX > $OUT/pmc_mix_write.log 2>&1 || { echo "pmc_mix_write failed"; exit 1; }
 find $OUT -name "*.csv" | head -30
+# the frame pipeline with the library's ROCTx ranges: trace domains only (kernel + memory-copy + marker), no counters;
+# summarised by `python tools/pipeline_trace.py --summarise-stages gpurun_out/prof_<tag>/pipe_f32 <tag> f32`
+PIPE="python3 $R/tools/pipeline_trace.py"
+rocprofv3 --kernel-trace --memory-copy-trace --marker-trace --output-format csv -d $OUT/pipe_f32 -- $PIPE f32 > $OUT/pipe_f32.log 2>&1 || { echo "pipe_f32 failed"; tail -5 $OUT/pipe_f32.log; exit 1; }
+rocprofv3 --kernel-trace --memory-copy-trace --marker-trace --output-format csv -d $OUT/pipe_u8 -- $PIPE > $OUT/pipe_u8.log 2>&1 || { echo "pipe_u8 failed"; tail -5 $OUT/pipe_u8.log; exit 1; }
+find $OUT -name "*marker*" | head

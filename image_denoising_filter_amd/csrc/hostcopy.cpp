@@ -57,13 +57,19 @@ void bounce_free(mid_bounce &b)
 // hipMemoryTypeHost covers hipHostMalloc and hipHostRegister memory alike; a pointer the runtime has never seen comes
 // back as hipMemoryTypeUnregistered (ROCm >= 6) or as hipErrorInvalidValue (older), which must not stay behind as the
 // thread's "last error".
-bool one_pinned(const void *p)
+enum class Kind { Pageable, Pinned, Device };
+
+Kind kind_of(const void *p)
 {
     hipPointerAttribute_t a;
     memset(&a, 0, sizeof a);
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return Kind::Pageable; }
+    if (a.type == hipMemoryTypeHost) return Kind::Pinned;
+    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeArray) return Kind::Device;
+    return Kind::Pageable;                        // unregistered, or managed memory (host-addressable: a plain memcpy works)
 }
+
+bool one_pinned(const void *p) { return kind_of(p) == Kind::Pinned; }
 
 }  // namespace
 
@@ -75,9 +81,17 @@ bool host_is_pinned(const void *p, size_t bytes)
     return one_pinned(p) && one_pinned((const char *)p + bytes - 1);
 }
 
+// A device pointer in the place of the host buffer would be memcpy'd by the CPU below: refuse it instead of crashing.
+static int refuse_device(const void *host, const char *what)
+{
+    if (kind_of(host) == Kind::Device) return set_error(MID_ERR_INVALID, "%s: the host-side pointer %p is device memory", what, host);
+    return MID_OK;
+}
+
 int copy_h2d(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t s)
 {
     if (bytes == 0) return MID_OK;
+    if (int rc = refuse_device(src, "host-to-device copy")) return rc;
     if (host_is_pinned(src, bytes)) {
         MID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
         return MID_OK;
@@ -100,6 +114,7 @@ int copy_h2d(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t
 int copy_d2h(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t s)
 {
     if (bytes == 0) return MID_OK;
+    if (int rc = refuse_device(dst, "device-to-host copy")) return rc;
     if (host_is_pinned(dst, bytes)) {
         MID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
         return MID_OK;

@@ -74,6 +74,18 @@ def test_pinned_registered_and_straddling_sources_all_arrive(ctx):
     assert np.array_equal(out3, data)
 
 
+def test_a_device_pointer_in_the_host_slot_is_refused_not_dereferenced(ctx):
+    """The bounce path reads / writes the "host" buffer with the CPU; handed a device pointer by mistake it must say so."""
+    a, b = ctx.alloc(1 << 20), ctx.alloc(1 << 20)
+    try:
+        assert mid.lib.mid_memcpy_h2d(ctx.handle, a.ptr, b.ptr, 1 << 20, None) != 0
+        assert b"device memory" in mid.lib.mid_last_error()
+        assert mid.lib.mid_memcpy_d2h(ctx.handle, b.ptr, a.ptr, 1 << 20, None) != 0
+        assert mid.lib.mid_memcpy_h2d(ctx.handle, a.ptr, None, 16, None) != 0                 # NULL stays an error as well
+    finally:
+        a.free(); b.free()
+
+
 def test_freshly_mapped_and_freed_frames_one_after_another(ctx):
     """The allocation pattern of the run that aborted in round 4 (LABNOTES R5.1): a 33 MB NumPy array is mmap'd, copied to the
     device, freed (munmap), and the next one lands on the same addresses.  With the bounce buffers the runtime never maps

@@ -36,9 +36,12 @@ namespace {
 
 // `n` device buffers of at least `bytes` each from the context's cache.  Every pipeline call ends with all four streams
 // synchronised, so whatever the cache holds is idle when the next call (serialised by pipe.mu) resizes it.
+// Shrink rule: buffers MORE than four times larger than this call needs are given back and reallocated at the size needed (a caller
+// that moves from 1080p RGBA32F frames to thumbnails does not keep 400 MB of HBM for them), while alternating between RGBA32F
+// and RGBA8 sequences of one frame size -- exactly a factor of four -- keeps the larger set and allocates nothing.
 int reserve(mid_pipe_set &s, size_t n, size_t bytes)
 {
-    if (bytes > s.bytes) {
+    if (bytes > s.bytes || (s.bytes > 4 * bytes && !s.p.empty())) {
         for (void *q : s.p) (void)hipFree(q);
         s.p.clear();
         s.bytes = bytes;

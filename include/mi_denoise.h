@@ -104,7 +104,9 @@ typedef struct mid_ctx mid_ctx;   /* opaque; bound to one HIP device */
 int         mid_ctx_create(int device, mid_ctx **out);
 void        mid_ctx_destroy(mid_ctx *ctx);
 /* Frees the device buffers and events the frame pipeline (mid_sequence_nlm*, mid_nlm_multiframe) keeps in the context
- * between calls -- at 1080p RGBA32F and k = 2 about 400 MB; the next pipeline call allocates again. */
+ * between calls -- at 1080p RGBA32F and k = 2 about 400 MB -- and the 32 MiB of page-locked bounce buffers; the next call
+ * allocates again.  Without it the cache follows the calls: it grows to the largest frame size seen, and a call whose frames
+ * are more than four times smaller than the cached buffers gives those back and keeps buffers of its own size. */
 int         mid_ctx_release_cached(mid_ctx *ctx);
 const char *mid_last_error(void);
 int         mid_version(void);

@@ -148,3 +148,31 @@ def test_frames_decoded_straight_into_pinned_memory(ctx, tmp_path):
     im = Image()
     assert mid.lib.mid_image_load_pinned(ctx.handle, str(bad).encode(), ctypes.byref(im)) == 5 and not im.data
     assert mid.lib.mid_image_load_pinned(ctx.handle, str(tmp_path / "nope.png").encode(), ctypes.byref(im)) == 5
+
+
+def test_pipeline_cache_follows_the_frame_size_down_as_well_as_up(ctx):
+    """the per-context cache grew to the largest call and never shrank.  Now a call whose frames are more than four
+    times smaller than the cached buffers releases them (RGBA32F <-> RGBA8 at one frame size, exactly 4x, keeps the larger set):
+    device memory comes back without mid_ctx_release_cached, and results do not depend on what the cache held before."""
+    import torch
+    rng = np.random.default_rng(12)
+    big = [synth_hdr(rng, 1080, 1920) * 0.3 for _ in range(3)]
+    small = [synth_hdr(rng, 64, 96) * 0.3 for _ in range(3)]
+    ctx.release_cached()
+    want_small, _ = ctx.sequence_nlm(small, k=1)
+    ctx.release_cached()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    ctx.sequence_nlm(big, k=1)
+    free_big = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free_big > 150e6                                   # ring of 3 + 4 output slots of 33 MB each
+    got_small, _ = ctx.sequence_nlm(small, k=1)
+    free_small = torch.cuda.mem_get_info(0)[0]
+    assert free_small - free_big > 150e6, (free0, free_big, free_small)   # the 1080p buffers were given back
+    assert all(np.array_equal(a, b) for a, b in zip(got_small, want_small))
+    # a factor of exactly four (same frames as RGBA8) keeps the larger buffers: nothing is reallocated
+    ctx.sequence_nlm(big, k=1)
+    free_a = torch.cuda.mem_get_info(0)[0]
+    ctx.sequence_nlm([np.clip(f * 255, 0, 255).astype(np.uint8) for f in big], k=1, out_u8=True)
+    assert torch.cuda.mem_get_info(0)[0] == free_a
+    ctx.release_cached()

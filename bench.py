@@ -235,9 +235,19 @@ def _cpu_reference_bilateral(oracle):
         for th in thread_set:
             rows = 360 if th == min(8, nproc) and radius == 10 else max(2 * radius + 8, min(360, int(0.2 * th * 441 / taps * 0.6e6 / W) // 4 * 4))
             leg(f"C2 1920x{rows} RGBA32F strip of the 1080p frame", frame[:rows], radius, th, 2.5)
+    # once, for context: the same loop with the reference's OWN compile flags -- "-fopenmp -g", no optimisation level
+    # (CMakeLists.txt:31) -- at its default radius and thread count, on a thin strip
+    as_shipped = None
+    if kind == "reference" and oracle.have_ref_as_shipped():
+        strip = frame[:40]
+        t0 = time.perf_counter()
+        oracle.ref_cpu_bilateral(strip, 10, min(8, nproc), as_shipped=True)
+        dt = time.perf_counter() - t0
+        as_shipped = {"flags": "-O0 -g -fopenmp (the reference's CMakeLists.txt:31)", "radius": 10, "threads": min(8, nproc),
+                      "Mpixel/s": round(40 * W / 1e6 / dt, 4), "sample_pixels": 40 * W, "seconds_per_run": round(dt, 4)}
     head = [l for l in legs if l["radius"] == 10 and l["threads"] == min(8, nproc)][0]
     return {"value": head["Mpixel/s"], "unit": "Mpixel/s", "cores": head["threads"], "kind": kind,
-            "legs": legs,
+            "legs": legs, "as_shipped_build": as_shipped,
             "sample": f"reference CPU bilateral loop (r=10, sigma_s=10, sigma_c=0.2, {head['threads']} OpenMP threads, -O2) "
                       f"on a 1920x360 RGBA32F strip, median of {head['runs']} runs; `legs` = SURVEY 8d's table "
                       "(C1 r=4, C2 r=8 and r=10, threads 1 / 8 / all)"}

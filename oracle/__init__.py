@@ -142,11 +142,17 @@ def have_ref():
     return os.path.exists(_REF)
 
 
-def ref_cpu_bilateral(img, radius=10, threads=1):
-    """The reference's own loop (sigma_s=10, sigma_c=0.2 are literals inside the slice)."""
-    if not have_ref():
-        raise RuntimeError("oracle/_ref/libref_cpu_bilateral.so has not been built (needs /root/reference)")
-    ref = ctypes.CDLL(_REF)
+def have_ref_as_shipped():
+    return os.path.exists(_REF.replace(".so", "_O0.so"))
+
+
+def ref_cpu_bilateral(img, radius=10, threads=1, as_shipped=False):
+    """The reference's own loop (sigma_s=10, sigma_c=0.2 are literals inside the slice).  as_shipped: the build with the
+    reference's own compile flags ("-fopenmp -g", no optimisation level: CMakeLists.txt:31) instead of -O2."""
+    path = _REF.replace(".so", "_O0.so") if as_shipped else _REF
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} has not been built (needs /root/reference)")
+    ref = ctypes.CDLL(path)
     img, p = _f32(img)
     h, w = _hw(img)
     out = np.empty_like(img)

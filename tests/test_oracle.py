@@ -35,6 +35,17 @@ def test_cpu_bilateral_matches_reference_live(shape, R):
     assert np.array_equal(oracle.cpu_bilateral(img, R, 10.0, 0.2, True, 2), oracle.ref_cpu_bilateral(img, R, 2))
 
 
+@pytest.mark.skipif(not (oracle.have_ref() and oracle.have_ref_as_shipped()), reason="oracle/_ref not built (no /root/reference on this box)")
+def test_reference_loop_gives_the_same_bits_at_its_own_compile_flags():
+    """The reference ships "-fopenmp -g" with no optimisation level (CMakeLists.txt:31); the checker and the timed baseline use -O2.
+    The loop's arithmetic is libm calls in double, stored to float: the two builds agree bit for bit, so the -O2 timing is the
+    same computation (bench.py quotes the -O0 rate once beside it)."""
+    rng = np.random.default_rng(9)
+    img = rng.random((37, 53, 4), dtype=np.float32) * 2.0
+    for R, th in ((10, 1), (4, 3)):
+        assert np.array_equal(oracle.ref_cpu_bilateral(img, R, th), oracle.ref_cpu_bilateral(img, R, th, as_shipped=True))
+
+
 def test_cpu_bilateral_reference_quirks():
     """Border stays Pixel{} = 0, alpha forced to 1, blue does not enter the range distance."""
     rng = np.random.default_rng(3)

@@ -94,22 +94,23 @@ def _same_code(profile, key, name, fp):
     return None
 
 
-def load_traffic(frames_per_launch, fp):
+def load_traffic(frames_per_launch, fp, workload="nlm"):
     """(HBM bytes per launch, where that figure comes from).  PMC counters cannot be read from inside an
     un-profiled run, so the figure is the one measured by the committed rocprofv3 `--pmc` passes of this same
     command (profiles/*_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); `traffic_source` in the JSON
     line says so, with the file and its date.  (None, reason) when no profile matches the launch shape or the
     profile was taken on different kernel code than the library now loaded holds (`fp`)."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    pattern = "r*_traffic.json" if workload == "nlm" else f"r*_traffic_{workload}.json"
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not cands:
-        return None, "no profiles/r*_traffic.json"
+        return None, f"no profiles/{pattern}"
     try:
         t = json.load(open(cands[-1]))
         stale = _same_code(t, "kernel_code_sha256", os.path.basename(cands[-1]), fp)
         if stale:
             return None, stale
-        if t.get("algorithmic_bytes_per_launch") != frames_per_launch * NPIX * NLM_BYTES_PER_PX:
+        if t.get("algorithmic_bytes_per_launch") != frames_per_launch * NPIX * NLM_BYTES_PER_PX:   # (32 B/px for both workloads)
             return None, f"{os.path.basename(cands[-1])} was measured for a different launch shape"
         when = t.get("date") or time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(cands[-1])))
         return round(t["traffic_bytes_per_launch"]), (f"profiles/{os.path.basename(cands[-1])} ({when}): rocprofv3 --pmc FETCH_SIZE / "
@@ -130,10 +131,11 @@ def load_utilisation(workload, fp):
         return {"valu_util": None, "lds_util": None, "utilisation_source": "no profiles/r*_utilisation.json"}
     try:
         u = json.load(open(cands[-1]))
-        if workload == "nlm":
-            stale = _same_code(u, "bench_kernel_code_sha256", os.path.basename(cands[-1]), fp)
-            if stale:
-                return {"valu_util": None, "lds_util": None, "utilisation_source": stale}
+        by = dict(u.get("bench_kernel_code_sha256_by_workload") or {})
+        by.setdefault("nlm", u.get("bench_kernel_code_sha256"))
+        stale = _same_code({"h": by.get(workload)}, "h", os.path.basename(cands[-1]), fp)
+        if stale:
+            return {"valu_util": None, "lds_util": None, "utilisation_source": stale}
         k = u["kernels"]["nlm_bench" if workload == "nlm" else "bilateral_r8_linear"]
         return {"valu_util": k["valu_issue_util"], "valu_util_at_occupancy_prices": k.get("valu_issue_util_at_occupancy"),
                 "cycles_per_wave_offset": {q: k["cycles_per_wave_offset"][q] for q in ("measured", "floor", "at_occupancy_prices")} if k.get("cycles_per_wave_offset") else None,
@@ -540,7 +542,8 @@ def main():
     px_per_launch = F * NPIX // launches_per_step
     avg_launch_s /= launches_per_step        # the timers bracket one step = launches_per_step back-to-back launches
     fp = loaded_kernel_fingerprint(mid.LIB_PATH, args.workload)
-    traffic, traffic_source = load_traffic(F, fp) if args.workload == "nlm" else (None, "not profiled for this workload")
+    # (nlm: one launch covers F frames; bilateral: one frame per launch)
+    traffic, traffic_source = load_traffic(F if args.workload == "nlm" else 1, fp, args.workload)
     res = {
         "metric": metric,
         "value": round(value, 2), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

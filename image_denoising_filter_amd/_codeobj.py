@@ -19,8 +19,10 @@ import sys
 
 _MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 # nlm_strip_kernel<SLO=-10, SHI=11, PLO=-3, PHI=4, R=8, NW=4, FMT=0 (RGBA32F), FUSED, !MULTI, !HALF>: bench.py's timed launch
+# bilateral_kernel<R=8, P=2, NW=8, FMT=0 (RGBA32F), LINEAR, MODE=0, BilOne>: `bench.py --workload bilateral`'s launch
 BENCH_KERNELS = {
     "nlm": "_ZN3mid16nlm_strip_kernelILin10ELi11ELin3ELi4ELi8ELi4ELi0ELb1ELb0ELb0EEEvNS_7NlmArgsE",
+    "bilateral": "_ZN3mid16bilateral_kernelILi8ELi2ELi8ELi0ELb1ELi0ENS_6BilOneEEEvNS_7BilArgsET5_",
 }
 
 
@@ -106,4 +108,6 @@ def fingerprint(lib_path, workload="nlm"):
 if __name__ == "__main__":
     import os
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmi_denoise.so")
-    print(json.dumps(fingerprint(path), indent=1))
+    out = fingerprint(path, "nlm")                              # top level: the headline kernel (as since round 5)
+    out["workloads"] = {w: fingerprint(path, w) for w in BENCH_KERNELS}
+    print(json.dumps(out, indent=1))

@@ -126,6 +126,23 @@ if dom:
              "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"}
         json.dump(t, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
         print(json.dumps(t, indent=1))
+# ---- traffic of the bilateral r=8 linear launch (`bench.py --workload bilateral`; north_star: "achieved HBM GB/s (bilateral)") ----
+bil = [k for k in pmc if "bilateral_kernel<8, 2, 8, 0, true, 0, mid::BilOne>" in k[0] and "FETCH_SIZE" in pmc[k] and "WRITE_SIZE" in pmc[k]]
+if bil:
+    d = pmc[bil[0]]
+    fetch_kb = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
+    write_kb = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+    fpb = (FP or {}).get("workloads", {}).get("bilateral")
+    tb = {"kernel": bil[0][0], "grid": bil[0][1], "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB": write_kb,
+          "read_bytes_corrected": fetch_kb * 1024 * 2, "write_bytes": write_kb * 1024,
+          "traffic_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
+          "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
+          "algorithmic_bytes_per_launch": 1920 * 1080 * 32,
+          "date": __import__("time").strftime("%Y-%m-%d", __import__("time").gmtime()),
+          **({"kernel_symbol": fpb["kernel_symbol"], "kernel_code_sha256": fpb["kernel_code_sha256"]} if fpb else {}),
+          "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (one pass each) -- python3 tools/profile_kernels.py 3 (one 1080p frame per launch, r = 8, linear addressing)"}
+    json.dump(tb, open(os.path.join(dst, f"{tag}_traffic_bilateral.json"), "w"), indent=1)
+    print(json.dumps(tb, indent=1))
 # ---- utilisation from counters (north_star: "LDS/VALU utilisation (NLM, compute-bound) against gfx950 peaks") ------------
 # Units (MI355X_MICROARCH.md, rocprofv3 PMC): GRBM_GUI_ACTIVE is summed over the 8 XCDs -> /8 = shader cycles of the launch;
 # SQ_BUSY_CYCLES is summed over the 32 shader engines, in cycles; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are per-wave
@@ -264,6 +281,7 @@ for name, key, cls in (("nlm_bench", pick("nlm_strip_kernel<-10, 11, -3, 4, 8, 4
             util["kernels"][name] = u
 if FP:
     util["bench_kernel_symbol"], util["bench_kernel_code_sha256"] = FP["kernel_symbol"], FP["kernel_code_sha256"]
+    util["bench_kernel_code_sha256_by_workload"] = {w_: f_["kernel_code_sha256"] for w_, f_ in FP.get("workloads", {}).items()}
 if util["kernels"]:
     json.dump(util, open(os.path.join(dst, f"{tag}_utilisation.json"), "w"), indent=1)
     for n_, u in util["kernels"].items():

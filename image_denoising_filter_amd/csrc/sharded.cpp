@@ -8,11 +8,15 @@
 // ONE exchange step -- ncclSend/ncclRecv inside one group, point to point with the neighbouring rank(s); no all-reduce,
 // no all-gather -- after which the rank filters its block with the same kernels as a single GPU does.
 //
-//   stream (caller's)   : [e0] interior outputs ................ [wait e1] boundary outputs
+//   stream (caller's)   : [e0] interior outputs ............................ [wait b1] done
 //   exchange stream     : [wait e0] group{recv halo, send edges} [e1]
+//   boundary stream     : [wait e0] [wait e1] boundary outputs ....... [b1]
 //
 // Interior outputs (windows inside the rank's own block) are launched while the halo is in flight; the <= 2k boundary
-// outputs wait for it.  The launch plan (which outputs are interior, which frame table each launch sees) is the one
+// outputs wait for it ON THEIR OWN STREAM, so that their workgroups fill the tail of the interior launch instead of
+// queueing behind it: at 8 frames per rank (64 frames on 8 GPUs, k = 2) the three launches are 9.03 + 4.5 + 4.5 rounds of
+// workgroups -- 20.0 ms back to back on one stream, 18.8 ms with the boundary launches on a second one, which is what ONE
+// launch over the 8 outputs takes (tools/boundary_stream_probe.py, LABNOTES R5.5).  The caller's stream joins at the end.  The launch plan (which outputs are interior, which frame table each launch sees) is the one
 // image_denoising_filter_amd/sharding.py::block_launch_plan states and the gloo tests pin; mid_shard_* expose it as pure
 // host functions so that the C++ and Python statements are tested against each other on the CPU.
 //
@@ -193,6 +197,9 @@ struct mid_comm {
     hipStream_t xs = nullptr;               // exchange stream (highest priority the device offers: see comm_finish_create)
     int xs_priority = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr, x0 = nullptr;
+    hipStream_t bs = nullptr;               // boundary stream: the launches that wait for the halo run here, beside the interior launches' tail
+    hipEvent_t b1 = nullptr;                // end of the boundary launches on bs; the caller's stream waits for it before `done`
+    bool bs_used = false;                   // this call queued something on bs (the join is then owed, also on an error path)
     hipEvent_t i1 = nullptr;                // end of the interior launches on the caller's stream (timeline only)
     hipEvent_t done = nullptr;              // end of the last sharded call's launches, on the stream it was issued on
     bool have_i1 = false, have_done = false;
@@ -227,6 +234,8 @@ static int comm_finish_create(mid_comm *c)
     MID_HIP(hipEventCreate(&c->x0));
     MID_HIP(hipEventCreate(&c->i1));
     MID_HIP(hipEventCreate(&c->done));
+    MID_HIP(hipStreamCreateWithFlags(&c->bs, hipStreamNonBlocking));
+    MID_HIP(hipEventCreateWithFlags(&c->b1, hipEventDisableTiming));
     return MID_OK;
 }
 
@@ -347,6 +356,8 @@ extern "C" int mid_comm_destroy(mid_comm *c)
     if (c->e1) (void)hipEventDestroy(c->e1);
     if (c->x0) (void)hipEventDestroy(c->x0);
     if (c->i1) (void)hipEventDestroy(c->i1);
+    if (c->b1) (void)hipEventDestroy(c->b1);
+    if (c->bs) { (void)hipStreamSynchronize(c->bs); (void)hipStreamDestroy(c->bs); }
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->xs) (void)hipStreamDestroy(c->xs);
     delete c;
@@ -446,6 +457,11 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
         ~Finish()
         {
             if (!armed) return;
+            if (c->bs_used) {                                      // the caller's stream continues only after the boundary stream's work
+                if (hipEventRecord(c->b1, c->bs) != hipSuccess || hipStreamWaitEvent(s, c->b1, 0) != hipSuccess)
+                    (void)hipStreamSynchronize(c->bs);             // (a broken device: fall back to a host-side join)
+                c->bs_used = false;
+            }
             c->have_done = hipEventRecord(c->done, s) == hipSuccess;
             c->last_stream = s; c->has_last = true;
         }
@@ -477,11 +493,19 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
         return nullptr;
     };
     for (int phase = 1; phase >= 0; --phase) {                    // interior launches first, then (after the halo) the boundary ones
+        hipStream_t ls = b.s;
         if (phase == 0) {
-            // every interior launch is on the stream by now; only here is the stream told to wait for the exchange
+            // every interior launch is on the caller's stream by now; the boundary launches go to the boundary stream, which is
+            // ordered behind the block's frames (e0) and -- only here -- told to wait for the exchange
             MID_HIP(hipEventRecord(c->i1, b.s));
             c->have_i1 = true;
-            if (c->timed) { MID_HIP(hipStreamWaitEvent(b.s, c->e1, 0)); c->issued += 'W'; }
+            bool any = false;
+            for (const Launch &L : plan) any = any || !L.interior;
+            if (!any) break;
+            ls = c->bs;
+            c->bs_used = true;
+            MID_HIP(hipStreamWaitEvent(c->bs, c->e0, 0));
+            if (c->timed) { MID_HIP(hipStreamWaitEvent(c->bs, c->e1, 0)); c->issued += 'W'; }
         }
         for (const Launch &L : plan) {
             if (L.interior != phase) continue;
@@ -490,7 +514,7 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
                 tbl[f - L.w_lo] = frame_ptr(f);
                 MID_REQUIRE(tbl[f - L.w_lo], "nlm_temporal_sharded: frame %d is neither in the block nor in the halo (plan error)", f);
             }
-            if (int rc = mid_nlm_temporal(c->ctx, p, tbl.data(), (int)tbl.size(), k, L.first, L.count, out + L.off, b.s)) return rc;
+            if (int rc = mid_nlm_temporal(c->ctx, p, tbl.data(), (int)tbl.size(), k, L.first, L.count, out + L.off, ls)) return rc;
             c->issued += phase ? 'I' : 'B';
         }
     }
@@ -536,7 +560,7 @@ extern "C" int mid_comm_last_timeline(mid_comm *c, float t_ms[4])
 }
 
 // What the last sharded call put on its streams, in host issue order: 'X' the exchange group (exchange stream), 'I' an
-// interior launch, 'W' the launch stream's wait for the exchange, 'B' a boundary launch.  The overlap of halo and interior
+// interior launch (caller's stream), 'W' the boundary stream's wait for the exchange, 'B' a boundary launch (boundary stream).  The overlap of halo and interior
 // compute is structural when every 'I' precedes the 'W' (tests/test_gpu_sharded_multirank.py asserts it).
 extern "C" int mid_comm_last_issue_order(mid_comm *c, char *buf, size_t buflen)
 {

@@ -269,8 +269,10 @@ int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const void *host_t
  * mid_comm_last_timeline: (waits for the call) its device timeline in ms from the call's first event on the caller's stream:
  *   t[0] exchange start, t[1] exchange end (both 0 when nothing was exchanged), t[2] end of the interior launches, t[3] end of
  *   the last launch.  The share of the exchange hidden behind interior compute is (min(t[1], t[2]) - t[0]) / (t[1] - t[0]).
- * mid_comm_last_issue_order: what the call put on its streams, in host issue order -- 'X' exchange group, 'I' interior
- *   launch, 'W' the launch stream's wait for the exchange, 'B' boundary launch; every 'I' precedes the 'W' by construction.
+ * mid_comm_last_issue_order: what the call put on its streams, in host issue order -- 'X' exchange group (exchange stream), 'I'
+ *   interior launch (caller's stream), 'W' the wait for the exchange, 'B' boundary launch (both on the communicator's boundary
+ *   stream, so that boundary workgroups fill the interior launch's tail; the caller's stream joins it before the call's work is
+ *   complete on that stream); every 'I' precedes the 'W' by construction.
  * mid_comm_stream_priority: the exchange stream's priority and the device's range (numerically lower = higher); the stream
  *   is created with the highest, so RCCL's send/receive kernels are dispatched ahead of queued interior workgroups. */
 typedef struct mid_comm mid_comm;

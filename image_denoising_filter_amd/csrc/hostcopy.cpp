@@ -22,12 +22,26 @@ namespace {
 
 constexpr size_t kChunk = 8u << 20;      // two 8 MiB halves per direction: a chunk's DMA (~0.17 ms) hides under the next memcpy
 
+void bounce_drop(mid_bounce &b)           // caller holds b.mu
+{
+    for (int i = 0; i < 2; ++i) {
+        if (b.busy[i]) { (void)hipEventSynchronize(b.ev[i]); b.busy[i] = false; }
+        if (b.ev[i]) { (void)hipEventDestroy(b.ev[i]); b.ev[i] = nullptr; }
+        if (b.buf[i]) { (void)hipHostFree(b.buf[i]); b.buf[i] = nullptr; }
+    }
+    b.chunk = 0;
+}
+
 int bounce_prepare(mid_bounce &b)
 {
-    if (b.buf[0]) return MID_OK;
+    if (b.chunk) return MID_OK;             // (set last: a half-built set is never mistaken for a complete one)
     for (int i = 0; i < 2; ++i) {
-        MID_HIP(hipHostMalloc(&b.buf[i], kChunk, hipHostMallocDefault));
-        MID_HIP(hipEventCreateWithFlags(&b.ev[i], hipEventDisableTiming));
+        hipError_t e = hipHostMalloc(&b.buf[i], kChunk, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b.ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            bounce_drop(b);
+            return set_error(MID_ERR_HIP, "page-locked bounce buffer (%zu B): %s", kChunk, hipGetErrorString(e));
+        }
         b.busy[i] = false;
     }
     b.chunk = kChunk;
@@ -46,12 +60,7 @@ int bounce_wait(mid_bounce &b, int i)
 void bounce_free(mid_bounce &b)
 {
     std::lock_guard<std::mutex> lock(b.mu);
-    for (int i = 0; i < 2; ++i) {
-        if (b.busy[i]) { (void)hipEventSynchronize(b.ev[i]); b.busy[i] = false; }
-        if (b.ev[i]) { (void)hipEventDestroy(b.ev[i]); b.ev[i] = nullptr; }
-        if (b.buf[i]) { (void)hipHostFree(b.buf[i]); b.buf[i] = nullptr; }
-    }
-    b.chunk = 0;
+    bounce_drop(b);
 }
 
 // hipMemoryTypeHost covers hipHostMalloc and hipHostRegister memory alike; a pointer the runtime has never seen comes
@@ -69,30 +78,31 @@ Kind kind_of(const void *p)
     return Kind::Pageable;                        // unregistered, or managed memory (host-addressable: a plain memcpy works)
 }
 
-bool one_pinned(const void *p) { return kind_of(p) == Kind::Pinned; }
+// Both ends of the range must lie in pinned memory (a frame that straddles the end of a registered range is treated as
+// pageable: bounced, never handed to the runtime half-pinned).  A device pointer in the place of the host buffer would be
+// memcpy'd by the CPU in the bounce path: refused instead of crashing.
+int classify(const void *host, size_t bytes, const char *what, bool *pinned)
+{
+    const Kind k0 = kind_of(host);
+    if (k0 == Kind::Device) return set_error(MID_ERR_INVALID, "%s: the host-side pointer %p is device memory", what, host);
+    *pinned = k0 == Kind::Pinned && kind_of((const char *)host + bytes - 1) == Kind::Pinned;
+    return MID_OK;
+}
 
 }  // namespace
 
-// Both ends of the range must lie in pinned memory (a frame that straddles the end of a registered range is treated as
-// pageable: bounced, never handed to the runtime half-pinned).
 bool host_is_pinned(const void *p, size_t bytes)
 {
     if (!p || bytes == 0) return true;
-    return one_pinned(p) && one_pinned((const char *)p + bytes - 1);
-}
-
-// A device pointer in the place of the host buffer would be memcpy'd by the CPU below: refuse it instead of crashing.
-static int refuse_device(const void *host, const char *what)
-{
-    if (kind_of(host) == Kind::Device) return set_error(MID_ERR_INVALID, "%s: the host-side pointer %p is device memory", what, host);
-    return MID_OK;
+    return kind_of(p) == Kind::Pinned && kind_of((const char *)p + bytes - 1) == Kind::Pinned;
 }
 
 int copy_h2d(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t s)
 {
     if (bytes == 0) return MID_OK;
-    if (int rc = refuse_device(src, "host-to-device copy")) return rc;
-    if (host_is_pinned(src, bytes)) {
+    bool pinned = false;
+    if (int rc = classify(src, bytes, "host-to-device copy", &pinned)) return rc;
+    if (pinned) {
         MID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
         return MID_OK;
     }
@@ -114,8 +124,9 @@ int copy_h2d(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t
 int copy_d2h(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t s)
 {
     if (bytes == 0) return MID_OK;
-    if (int rc = refuse_device(dst, "device-to-host copy")) return rc;
-    if (host_is_pinned(dst, bytes)) {
+    bool pinned = false;
+    if (int rc = classify(dst, bytes, "device-to-host copy", &pinned)) return rc;
+    if (pinned) {
         MID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
         return MID_OK;
     }

@@ -100,7 +100,8 @@ def test_freshly_mapped_and_freed_frames_one_after_another(ctx):
         got = ctx.download(buf, (h, w, 4), np.float32)
         buf.free()
         assert got[0, 0, 0] == np.float32(i + 0.5) and got[-1, -1, -1] == np.float32(i + 0.5) and np.all(got == got[0, 0, 0])
-    assert len(addrs) < 12            # the allocator did reuse addresses: the pattern was exercised
+    # (glibc hands the munmap'd range straight back, so the 12 arrays usually share one or two addresses -- the pattern of the
+    # aborted run -- but nothing guarantees it, so it is not asserted)
 
 
 def test_threads_share_one_contexts_bounce_buffers(ctx):

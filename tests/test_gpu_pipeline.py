@@ -174,5 +174,5 @@ def test_pipeline_cache_follows_the_frame_size_down_as_well_as_up(ctx):
     ctx.sequence_nlm(big, k=1)
     free_a = torch.cuda.mem_get_info(0)[0]
     ctx.sequence_nlm([np.clip(f * 255, 0, 255).astype(np.uint8) for f in big], k=1, out_u8=True)
-    assert torch.cuda.mem_get_info(0)[0] == free_a
+    assert abs(torch.cuda.mem_get_info(0)[0] - free_a) < 16e6       # (no 33 MB buffer was freed or allocated; small runtime pools may move)
     ctx.release_cached()

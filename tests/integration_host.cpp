@@ -4,6 +4,8 @@
 // by tests/test_gpu_integration_host.py, which holds its outputs against the Python-driven calls of the same entry points.
 //   integration_host <mode> <w> <h> <hdr:0|1> <in.raw> <out.raw> [extra.raw ...]
 //   mode: bilateral | linear | layers (extras = RGBA8 layers) | nlm (extras = further frames; in.raw is the target)
+//         sharded (INTEGRATION.md "An animation over several GPUs", one rank: in.raw + extras are the sequence, k = 2; out.raw holds
+//         every output frame, then 4 floats: the call's device timeline from mid_comm_last_timeline)
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -46,6 +48,37 @@ try {
 
     mid_ctx *ctx = nullptr;
     MID_CHECK(mid_ctx_create(0, &ctx));
+    if (mode == "sharded") {
+        const int rank = 0, world = 1, nFrames = (int)imageData.size();
+        uint8_t id[MID_COMM_ID_BYTES];
+        if (rank == 0) MID_CHECK(mid_comm_unique_id(id));                   // ncclGetUniqueId
+        mid_comm *comm = nullptr;
+        MID_CHECK(mid_comm_create(ctx, id, rank, world, &comm));            // ncclCommInitRank on ctx's device
+        int start, count;
+        MID_CHECK(mid_shard_block(nFrames, world, rank, &start, &count));
+        std::vector<void *> dBlock(count), dOutv(count);
+        for (int i = 0; i < count; ++i) {
+            MID_CHECK(mid_alloc(ctx, inBytes, &dBlock[i]));
+            MID_CHECK(mid_alloc(ctx, outBytes, &dOutv[i]));
+            MID_CHECK(mid_memcpy_h2d(ctx, dBlock[i], hostPtr(start + i), inBytes, nullptr));
+        }
+        mid_nlm_params p{w, h, 0.5f, -7, 7, -3, 3, fmt};
+        MID_CHECK(mid_nlm_temporal_sharded(comm, &p, dBlock.data(), nFrames, /*k*/2, (mid_pixel *const *)dOutv.data(), nullptr));
+        MID_CHECK(mid_stream_sync(ctx, nullptr));
+        float t[4];
+        MID_CHECK(mid_comm_last_timeline(comm, t));
+        std::ofstream o(argv[6], std::ios::binary);
+        std::vector<Pixel> frame(size_t(w) * h);
+        for (int i = 0; i < count; ++i) {
+            MID_CHECK(mid_memcpy_d2h(ctx, frame.data(), dOutv[i], outBytes, nullptr));
+            o.write((const char *)frame.data(), (std::streamsize)outBytes);
+            mid_free(ctx, dBlock[i]); mid_free(ctx, dOutv[i]);
+        }
+        o.write((const char *)t, sizeof t);
+        MID_CHECK(mid_comm_destroy(comm));
+        mid_ctx_destroy(ctx);
+        return o.good() ? 0 : 3;
+    }
     void *dTarget = nullptr, *dOut = nullptr;
     MID_CHECK(mid_alloc(ctx, inBytes, &dTarget));
     MID_CHECK(mid_alloc(ctx, outBytes, &dOut));

@@ -55,6 +55,29 @@ def test_the_documented_call_sequence_gives_the_bytes_of_the_python_driven_calls
     assert np.array_equal(_run(exe, tmp_path, "nlm", hdr, t, frames[1:]), post(ctx.normalize(Wacc)))
 
 
+def test_the_multi_gpu_snippet_with_one_rank_over_real_rccl(ctx, exe, tmp_path):
+    """INTEGRATION.md "An animation over several GPUs": mid_comm_unique_id -> mid_comm_create -> mid_shard_block ->
+    mid_nlm_temporal_sharded -> mid_comm_last_timeline, from C++, with a 1-rank RCCL communicator (all this pool can offer): the
+    outputs are mid_nlm_temporal's over the whole sequence, and the timeline says "no exchange" (0, 0) and a positive end."""
+    rng = np.random.default_rng(5)
+    frames = [synth_hdr(rng, H, W) * 0.3 for _ in range(6)]
+    (tmp_path / "in.raw").write_bytes(frames[0].tobytes())
+    names = []
+    for i, f in enumerate(frames[1:]):
+        (tmp_path / f"f{i}.raw").write_bytes(f.tobytes())
+        names.append(str(tmp_path / f"f{i}.raw"))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([exe, "sharded", str(W), str(H), "1", str(tmp_path / "in.raw"), str(tmp_path / "out.raw")] + names,
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    raw = np.frombuffer((tmp_path / "out.raw").read_bytes(), np.float32)
+    outs, t = raw[:-4].reshape(6, H, W, 4), raw[-4:]
+    want = ctx.nlm_temporal(frames, k=2, search=(-7, 7), patch=(-3, 3))
+    assert all(np.array_equal(outs[i], want[i]) for i in range(6))
+    assert t[0] == 0 and t[1] == 0 and t[3] > 0 and t[2] <= t[3]
+
+
 def test_a_missing_input_is_a_runtime_error_and_exit_failure(exe, tmp_path):
     r = subprocess.run([exe, "bilateral", "8", "8", "1", str(tmp_path / "nope.raw"), str(tmp_path / "o.raw")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "unexpected size" in r.stderr

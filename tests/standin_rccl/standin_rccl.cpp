@@ -16,6 +16,9 @@
 // STANDIN_RCCL_DELAY_MS=<ms>: every receive is held back by a one-wave kernel that spins for about that long on the receiver's
 // exchange stream before the copy -- a slow wire, so that a test can see on the device timeline that interior launches do not
 // wait for the halo and boundary launches do (the kernel reads the 100 MHz wall clock and always terminates).
+// STANDIN_RCCL_COPY_WGS=<n>: the copy is done by a KERNEL of n workgroups x 256 threads instead of hipMemcpyAsync -- like RCCL's
+// own send/receive, which are kernels that have to find compute units beside whatever else the device runs
+// (tools/halo_overlap_probe.py uses it to see whether a busy device delays the exchange).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <condition_variable>
@@ -33,6 +36,18 @@ __global__ void standin_hold(long long ticks)      // wall_clock64: constant 100
 {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+__global__ void standin_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+int copy_workgroups()
+{
+    const char *e = getenv("STANDIN_RCCL_COPY_WGS");
+    const int n = e && *e ? atoi(e) : 0;
+    return n > 0 && n <= 4096 ? n : 0;
 }
 
 long long delay_ticks()
@@ -124,7 +139,10 @@ ncclResult_t flush()
             standin_hold<<<1, 64, 0, op.stream>>>(ticks);
             if (hipGetLastError() != hipSuccess) return ncclUnhandledCudaError;
         }
-        if (hipMemcpyAsync(op.buf, p->src, op.bytes, hipMemcpyDeviceToDevice, op.stream) != hipSuccess) return ncclUnhandledCudaError;
+        if (const int wgs = copy_workgroups(); wgs && op.bytes % 16 == 0 && ((uintptr_t)op.buf | (uintptr_t)p->src) % 16 == 0) {
+            standin_copy<<<wgs, 256, 0, op.stream>>>((const uint4 *)p->src, (uint4 *)op.buf, op.bytes / 16);
+            if (hipGetLastError() != hipSuccess) return ncclUnhandledCudaError;
+        } else if (hipMemcpyAsync(op.buf, p->src, op.bytes, hipMemcpyDeviceToDevice, op.stream) != hipSuccess) return ncclUnhandledCudaError;
         hipEvent_t done;
         if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError;
         if (hipEventRecord(done, op.stream) != hipSuccess) return ncclUnhandledCudaError;

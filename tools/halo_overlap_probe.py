@@ -35,9 +35,16 @@ for t in th: t.join(timeout=120)
 print("PROBE " + json.dumps({"rep": rep, "errs": errs}))
 '''
 standin = os.path.join(ROOT, "tests", "standin_rccl", "libstandin_rccl.so")
+# (wire delay ms per frame, frames, h, w, copy-kernel workgroups [0 = hipMemcpyAsync])
+CASES = (("0", 16, 270, 480, 0), ("30", 16, 270, 480, 0), ("10", 16, 1080, 1920, 0),
+         # the copy as a KERNEL, like RCCL's send/receive: first with nothing else to do (4 frames on 2 ranks at k = 2: every output is a
+         # boundary output, the exchange runs on an idle device), then beside the interior launches of 8 frames per rank
+         ("0", 4, 1080, 1920, 8), ("0", 16, 1080, 1920, 8), ("0", 4, 1080, 1920, 32), ("0", 16, 1080, 1920, 32))
 for lib in (sys.argv[1:] or [""]):
-    for delay, n, h, w in (("0", 16, 270, 480), ("30", 16, 270, 480), ("10", 16, 1080, 1920)):
-        env = dict(os.environ, MID_RCCL_LIBRARY=standin, STANDIN_RCCL_DELAY_MS=delay)
+    for delay, n, h, w, wgs in CASES:
+        env = dict(os.environ, MID_RCCL_LIBRARY=standin, STANDIN_RCCL_DELAY_MS=delay, GPU_MAX_HW_QUEUES="24")
+        if wgs:
+            env["STANDIN_RCCL_COPY_WGS"] = str(wgs)
         if lib:
             env["MID_LIB_PATH"] = os.path.abspath(lib)
         r = subprocess.run([sys.executable, "-c", code, ROOT, str(n), str(h), str(w)], env=env, capture_output=True, text=True, timeout=300)
@@ -47,7 +54,7 @@ for lib in (sys.argv[1:] or [""]):
             continue
         d = json.loads(line[0][6:])
         for rk, t in sorted(d["rep"].items()):
-            print(f"{os.path.basename(lib) or 'shipped':24s} {w}x{h} wire delay {delay:>2s} ms/frame rank {rk}: exchange {t['exchange_start_ms']:.2f}..{t['exchange_end_ms']:.2f}  "
+            print(f"{os.path.basename(lib) or 'shipped':24s} {n:2d} frames {w}x{h} wire delay {delay:>2s} ms/frame copy {('kernel x%d WGs' % wgs) if wgs else 'hipMemcpyAsync':15s} rank {rk}: exchange {t['exchange_start_ms']:.2f}..{t['exchange_end_ms']:.2f}  "
                   f"interior_end {t['interior_end_ms']:.2f}  end {t['end_ms']:.2f}  hidden {t['halo_hidden_frac']}  order {t['order']}  prio {t['priority']}", flush=True)
         if d["errs"]:
             print("   errors:", d["errs"])

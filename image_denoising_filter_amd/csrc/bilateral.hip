@@ -428,11 +428,7 @@ static int dispatch_radius(mid_ctx *ctx, int radius, BilArgs &a, hipStream_t s, 
     // independent waves (P = 2 rows per lane, 8 waves per workgroup) beat deeper register blocking.
     switch (radius) {
     case 4:  return launch_tiled<4, 2, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);    // BASELINE config 1 window
-    case 8:
-#ifdef MID_BIL_L8_P                        // development A/B only: another tile shape for the layer modes at r = 8 (tools/layers_steady_ab.py)
-        if constexpr (MODE != 0) return launch_tiled<8, MID_BIL_L8_P, MID_BIL_L8_NW, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);
-#endif
-        return launch_tiled<8, 2, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);           // BASELINE configs[1] and [3]
+    case 8:  return launch_tiled<8, 2, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);    // BASELINE configs[1] and [3] (layer modes: also best of six shapes, profiles/r05_ab_layer_tile_shapes.txt)
     case 10: return launch_tiled<10, 2, 16, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);  // CPU path window, src/main.cpp:1819
     case 20:                                                                 // TEXEL_WINDOW as shipped
         return launch_tiled<20, 1, 8, FMT, LINEAR, MODE, BT>(ctx, a, bt, n_frames, s);          // 80 KB tile: two workgroups per CU (or image + guide tile)

@@ -224,9 +224,6 @@ static int comm_finish_create(mid_comm *c)
 {
     int least = 0, greatest = 0;
     MID_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));         // numerically lower = higher priority
-#ifdef MID_XS_DEFAULT_PRIORITY                                                  // development A/B only (tools/halo_overlap_probe.py)
-    greatest = 0;
-#endif
     c->xs_priority = greatest;
     MID_HIP(hipStreamCreateWithPriority(&c->xs, hipStreamNonBlocking, greatest));
     MID_HIP(hipEventCreate(&c->e0));

@@ -1,7 +1,8 @@
 """Does work on the exchange stream delay the interior launches?  Two ranks (threads) on cuda:0 against the stand-in transport
 with its wire slowed down (STANDIN_RCCL_DELAY_MS): per rank the device timeline of one mid_nlm_temporal_sharded call.
    python tools/halo_overlap_probe.py [lib.so ...]      (fresh process per library, MID_LIB_PATH; "" = the shipped one)
-Used for LABNOTES R5.3: exchange stream at the highest priority (shipped) vs at the default priority (-DMID_XS_DEFAULT_PRIORITY)."""
+Used for LABNOTES R5.3: exchange stream at the highest priority (shipped) vs at the default priority (a build with
+-DMID_XS_DEFAULT_PRIORITY; the switch left csrc/sharded.cpp after the measurement, see tools/experiments/README.md)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''

@@ -102,3 +102,30 @@ def test_six_reference_modes_at_1080p_every_pixel(tmp_path, hdr):
     # not vacuous: the six modes are different filters
     assert not np.array_equal(outs[False][NAMES[0]], outs[False][NAMES[3]])
     assert not np.array_equal(outs[False][NAMES[3]], outs[False][NAMES[4]])
+
+
+@pytest.mark.parametrize("hdr", [True, False])
+def test_animation_mode_at_1080p_pinned_and_pageable_frames(tmp_path, hdr):
+    """--animation streams every frame through mid_sequence_nlm_range[_u8]: 33 MB (EXR) / 8 MB (PNG) per copy each way.  Default:
+    frames decoded into page-locked memory; `--pinned-mb 0`: every frame in ordinary memory, carried by the library's bounce
+    buffers.  Same files both ways, every pixel against the float64 temporal evaluation (PNG outputs: the u8 read-back
+    conversion runs on the device, compared within one LSB of the truncation boundary)."""
+    d, frames, _, ext = _make(tmp_path, hdr)
+    f32 = [f if hdr else f.astype(np.float32) / np.float32(255.0) for f in frames]
+    outs = {}
+    for label, extra in (("pinned", []), ("pageable", ["--pinned-mb", "0"])):
+        out = tmp_path / label
+        out.mkdir()
+        r = subprocess.run([CLI, str(d / f"Animation01_X_0000.{ext}"), "--animation", "--temporal-k", "1", "--outdir", str(out)] + extra,
+                           cwd=tmp_path, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert ("beyond the page-locked budget" in r.stdout) == (label == "pageable")
+        outs[label] = [mid.load_image(out / f"output-animation-Animation01_X_{i:04d}.{ext}") for i in range(N_FRAMES)]
+    for i in range(N_FRAMES):
+        assert np.array_equal(outs["pinned"][i], outs["pageable"][i]), i
+        want = f64.nlm_temporal_output(f32, i, 1, 0.5, (-7, 7), (-3, 3))
+        if hdr:
+            assert rel_err(outs["pinned"][i], want) < 2e-5, i
+        else:
+            diff = np.abs(outs["pinned"][i].astype(np.int16) - _pack_u8(want).astype(np.int16))
+            assert diff.max() <= 1 and (diff[..., :3] != 0).mean() < 1e-3, (i, int(diff.max()))

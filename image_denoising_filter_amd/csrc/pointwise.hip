@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) void pack_tail_kernel(const float *in, uint8_t
 
 static unsigned stream_grid(mid_ctx *ctx, size_t n)
 {
-    const size_t want = (n + 255) / 256, cap = (size_t)ctx->cu_count * 8;
+#ifndef MID_STREAM_CAP
+#define MID_STREAM_CAP 8
+#endif
+    const size_t want = (n + 255) / 256, cap = (size_t)ctx->cu_count * MID_STREAM_CAP;
     return (unsigned)(want < cap ? (want ? want : 1) : cap);
 }
 

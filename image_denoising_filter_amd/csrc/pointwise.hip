@@ -56,10 +56,8 @@ __global__ __launch_bounds__(256) void pack_tail_kernel(const float *in, uint8_t
 
 static unsigned stream_grid(mid_ctx *ctx, size_t n)
 {
-#ifndef MID_STREAM_CAP
-#define MID_STREAM_CAP 8
-#endif
-    const size_t want = (n + 255) / 256, cap = (size_t)ctx->cu_count * MID_STREAM_CAP;
+    // (8 workgroups per CU; 4, 16, 32 and "one pixel per thread" measure the same: profiles/r05_ab_stream_grid_cap.txt)
+    const size_t want = (n + 255) / 256, cap = (size_t)ctx->cu_count * 8;
     return (unsigned)(want < cap ? (want ? want : 1) : cap);
 }
 

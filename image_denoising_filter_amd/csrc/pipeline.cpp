@@ -19,7 +19,8 @@
 // (a gated chunk-launch alternative was measured in round 2 and removed: LABNOTES.md).  Host frames
 // allocated with mid_alloc_host (pinned) are DMA'd directly; pageable memory still works, but it is
 // moved through the context's page-locked bounce buffers (csrc/hostcopy.cpp: a host memcpy per 8 MiB
-// chunk, never the runtime's pin-on-the-fly path) and the host thread -- not the link -- sets the pace.
+// chunk, never the runtime's pin-on-the-fly path) and the host's memcpy rate -- not the link -- sets
+// the pace (uploads on the calling thread, pageable outputs on a helper thread of the call).
 //
 // Frame selection differs from the reference on purpose: frames are taken
 // in the order given, window t-k..t+k clipped at the sequence ends; the reference's "every
@@ -27,7 +28,9 @@
 // reproduced.
 #include "common.hpp"
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 using namespace mid;
@@ -147,10 +150,12 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
         MID_HIP(hipEventRecord(up1.ev[f - f_lo], ctx->upload));
         return MID_OK;
     };
-    // Pinned outputs: download(bi) is queued right behind compute(bi) and the host runs on.  Pageable outputs: copy_d2h
-    // returns only when the frame is in the caller's buffer, so download(bi) is issued one iteration late -- after
-    // compute(bi+1) and its uploads have been queued -- and the GPU keeps a launch in flight while the host copies out.
-    // d1[bi] is then recorded in iteration bi+1, still before compute(bi+DEPTH) asks for it.
+    // Pinned outputs: download(bi) is queued right behind compute(bi) and the host runs on.  Pageable outputs: copy_d2h returns
+    // only when the frame is in the caller's buffer (a host memcpy per chunk out of the bounce buffers), so those downloads run on
+    // a helper thread of this call: the calling thread keeps bouncing uploads in and queueing launches while the helper copies
+    // finished frames out -- the two memcpy streams overlap (16 x 1080p RGBA32F with pageable frames on both sides: 42.9 ms with
+    // both on one thread).  The helper takes batch bi once compute(bi) has been queued; compute(bi) is queued only when the helper
+    // has recorded d1[bi-DEPTH] (the output slot is free) -- the event order of the pinned case, kept by two counters.
     bool out_pinned = true;
     for (int i = 0; i < count; ++i) out_pinned = out_pinned && host_is_pinned(host_out[i], dl_bytes);
     auto download = [&](int bi) -> int {
@@ -162,6 +167,49 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
             if (int rc = copy_d2h(ctx, host_out[b0 - first + i], dout.p[(bi % DEPTH) * B + i], dl_bytes, ctx->download)) return rc;
         MID_HIP(hipEventRecord(d1.ev[bi], ctx->download));
         return MID_OK;
+    };
+    struct Helper {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        int issued = -1;                 // highest batch whose launch has been queued          (caller -> helper)
+        int done = -1;                   // highest batch whose download has finished, d1 recorded (helper -> caller)
+        bool stop = false;
+        int rc = MID_OK;
+        char err[512] = "";
+        ~Helper()
+        {
+            if (!th.joinable()) return;
+            { std::lock_guard<std::mutex> l(mu); stop = true; }
+            cv.notify_all();
+            th.join();                   // before DrainOnExit and before anything the download lambda refers to goes away
+        }
+    } helper;
+    const bool threaded = !out_pinned && overlap;
+    if (threaded) {
+        helper.th = std::thread([&] {
+            (void)hipSetDevice(ctx->device);
+            for (int bi = 0; bi < nb; ++bi) {
+                {
+                    std::unique_lock<std::mutex> l(helper.mu);
+                    helper.cv.wait(l, [&] { return helper.stop || helper.issued >= bi; });
+                    if (helper.issued < bi) return;          // stopped before this batch was launched
+                }
+                const int rc = download(bi);
+                {
+                    std::lock_guard<std::mutex> l(helper.mu);
+                    if (rc) { helper.rc = rc; snprintf(helper.err, sizeof helper.err, "%s", mid_last_error()); helper.stop = true; }
+                    else helper.done = bi;
+                }
+                helper.cv.notify_all();
+                if (rc) return;
+            }
+        });
+    }
+    // the helper's error, if any, becomes this thread's error
+    auto helper_failed = [&]() -> int {
+        std::lock_guard<std::mutex> l(helper.mu);
+        return helper.rc ? set_error(helper.rc, "%s", helper.err) : MID_OK;
     };
 
     for (int bi = 0; bi < nb; ++bi) {
@@ -181,7 +229,14 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
         // Output slot bi % DEPTH was written by batch bi-DEPTH and is read only by download(bi-DEPTH), which
         // itself waited for c1[bi-DEPTH]: d1[bi-DEPTH] therefore orders both the writer and the only reader of
         // the slot before this batch, whichever kernel stream they ran on.
-        if (bi >= DEPTH) MID_HIP(hipStreamWaitEvent(cs, d1.ev[bi - DEPTH], 0));
+        if (bi >= DEPTH) {
+            if (threaded) {              // d1[bi-DEPTH] must have been RECORDED before a stream can be told to wait for it
+                std::unique_lock<std::mutex> l(helper.mu);
+                helper.cv.wait(l, [&] { return helper.stop || helper.done >= bi - DEPTH; });
+                if (helper.rc) { l.unlock(); return helper_failed(); }
+            }
+            MID_HIP(hipStreamWaitEvent(cs, d1.ev[bi - DEPTH], 0));
+        }
 
         const int lo = b0 - k < 0 ? 0 : b0 - k;
         const void *tbl[kMaxFrames];
@@ -199,8 +254,10 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
 
         while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }
 
-        if (out_pinned || !overlap) { if (int rc = download(bi)) return rc; }
-        else if (bi >= 1) { if (int rc = download(bi - 1)) return rc; }
+        if (threaded) {
+            { std::lock_guard<std::mutex> l(helper.mu); helper.issued = bi; }
+            helper.cv.notify_all();
+        } else if (int rc = download(bi)) return rc;
 
         if (!overlap) {   // the reference's behaviour: a fence wait after every submit (src/main.cpp:1092)
             MID_HIP(hipStreamSynchronize(ctx->upload));
@@ -208,7 +265,14 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
             MID_HIP(hipStreamSynchronize(ctx->download));
         }
     }
-    if (!out_pinned && overlap) { if (int rc = download(nb - 1)) return rc; }
+    if (threaded) {
+        {
+            std::unique_lock<std::mutex> l(helper.mu);
+            helper.cv.wait(l, [&] { return helper.stop || helper.done >= nb - 1; });
+        }
+        helper.th.join();
+        if (int rc = helper_failed()) return rc;
+    }
     {
         Range r("drain");
         MID_HIP(hipStreamSynchronize(ctx->upload));

@@ -199,3 +199,23 @@ def test_two_threads_run_the_pipeline_on_one_context_while_a_third_releases_its_
     stop.set()
     r.join(60)
     assert not errs and not any(t.is_alive() for t in ts + [r]), errs
+
+
+def test_an_error_on_the_pipelines_helper_thread_ends_the_call_with_that_error_not_a_hang(ctx):
+    """Pageable outputs are copied out by a helper thread of the call.  One of seven output pointers is a DEVICE pointer: the
+    helper's copy refuses it, the call returns that error on the calling thread (not a hang, not a crash), and the context
+    runs the next call as if nothing had happened."""
+    rng = np.random.default_rng(4)
+    frames = [synth_hdr(rng, 270, 480) * 0.3 for _ in range(7)]
+    want, _ = ctx.sequence_nlm(frames, k=1)
+    outs = [np.empty((270, 480, 4), np.float32) for _ in range(7)]
+    dev = ctx.alloc(270 * 480 * 16)
+    ptrs = [o.ctypes.data for o in outs]
+    ptrs[4] = dev.ptr
+    with pytest.raises(mid.MidError) as e:
+        ctx.sequence_nlm_pinned([f.ctypes.data for f in frames], ptrs, 480, 270, mid.FMT_RGBA32F, k=1)
+    assert "device memory" in str(e.value)
+    dev.free()
+    assert all(np.array_equal(outs[i], want[i]) for i in range(4))           # the frames before the bad one were delivered
+    got, _ = ctx.sequence_nlm(frames, k=1, pinned=False, pinned_out=False)
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))

@@ -284,6 +284,50 @@ def cpu_baseline(workload="nlm"):
     return out
 
 
+def native_temporal_report(rows, n_seq, world, rehearse, order, prio, rc_ver, frames_per_rank):
+    """The two objects the C++ RCCL path contributes to the line, from the per-rank rows gathered after the timed repetitions
+    (a pure function: tests/test_bench_counters.py feeds it rows of 2 and 8 ranks, a world this pool cannot run).  Row layout:
+    [seconds per sequence, halo bytes received, halo bytes sent, exchange ms, bit-identical (1/0), exchange start ms, exchange end ms,
+    interior end ms, call end ms, halo_hidden_frac or -1, ncclCommCount, ncclCommUserRank]."""
+    te = max(r[0] for r in rows)
+    nat = {"Mpixel/s_out": round(n_seq * NPIX / 1e6 / te, 1), "frames": n_seq,
+           "ms_per_sequence": round(te * 1e3, 3),
+           "halo_bytes_recv_per_rank": [int(r[1]) for r in rows],
+           "halo_bytes_sent_per_rank": [int(r[2]) for r in rows],
+           "exchange_ms_per_rank": [round(r[3], 4) for r in rows],
+           "bit_identical_to_single_launch_per_rank": [bool(r[4]) for r in rows],
+           # device timeline of one call, ms from the call's first event on the launch stream, per rank
+           "timeline_ms_per_rank": [{"exchange_start": round(r[5], 4), "exchange_end": round(r[6], 4),
+                                     "interior_end": round(r[7], 4), "end": round(r[8], 4)} for r in rows],
+           "halo_hidden_frac_per_rank": [None if r[9] < 0 else round(r[9], 4) for r in rows],
+           "issue_order_rank0": order, "exchange_stream_priority": {"priority": prio[0], "least": prio[1], "greatest": prio[2]},
+           "rccl": {"comm_count_per_rank": [int(r[10]) for r in rows], "user_rank_per_rank": [int(r[11]) for r in rows], "version": rc_ver},
+           "path": "C++: mid_comm_create (ncclCommInitRank via dlopen) + mid_nlm_temporal_sharded "
+                   "(ncclSend/ncclRecv in one group on the highest-priority exchange stream, interior launches meanwhile, "
+                   "boundary launches on their own stream)"}
+    # The sharded path at the top level of the line (the headline above is replicas: weak scaling of independent batches):
+    # BASELINE configs[4] -- ONE 64-frame 1080p sequence, temporal +-2 -- split over the ranks; the same job at every N.
+    hid = [x for x in nat["halo_hidden_frac_per_rank"] if x is not None]
+    strong = {
+        "workload": "nlm_temporal_k2_64_frames_1080p_hdr (BASELINE configs[4]): one sequence, contiguous frame blocks per rank, halo over RCCL",
+        "metric": "output Mpixel/s (64 x 1920 x 1080 / max-over-ranks seconds per sequence)",
+        "value": nat["Mpixel/s_out"], "unit": "Mpixel/s", "n_gpus": world, "scaling": "strong", "ms_per_sequence": nat["ms_per_sequence"],
+        "frames_per_rank": list(frames_per_rank),
+        "bit_identical_to_single_launch_per_rank": nat["bit_identical_to_single_launch_per_rank"],
+        "bytes_on_the_wire": int(sum(nat["halo_bytes_sent_per_rank"])),
+        "rccl_comm_count": nat["rccl"]["comm_count_per_rank"], "rccl_version": rc_ver,
+        "exchange_ms_per_rank": nat["exchange_ms_per_rank"],
+        "halo_hidden_frac": (round(min(hid), 4) if hid else None),
+        "halo_hidden_frac_per_rank": nat["halo_hidden_frac_per_rank"],
+        "halo_hidden_frac_def": "share of a rank's exchange (first receive posted .. last transfer complete, device timeline) that ran while "
+                                "its interior launches were still executing: (min(exchange_end, interior_end) - exchange_start) / "
+                                "(exchange_end - exchange_start); the value is the worst rank's; null with one rank (nothing is exchanged)",
+        "hardware_status": ("measured in this run" if world > 1 and not rehearse else
+                            "one rank: no exchange took place -- the N >= 2 figures are unmeasured on hardware until a multi-GPU run"),
+    }
+    return nat, strong
+
+
 class _DryContext:
     """Stands in for the C-ABI context in --dry-run: records what would be launched, computes nothing."""
     def __init__(self):
@@ -837,42 +881,10 @@ def main():
                 rows = [[float(x) for x in a.tolist()] for a in allr]
             else:
                 rows = [per_rank]
-            te = max(r[0] for r in rows)
-            nat = {"Mpixel/s_out": round(n_seq * NPIX / 1e6 / te, 1), "frames": n_seq,
-                   "ms_per_sequence": round(te * 1e3, 3),
-                   "halo_bytes_recv_per_rank": [int(r[1]) for r in rows],
-                   "halo_bytes_sent_per_rank": [int(r[2]) for r in rows],
-                   "exchange_ms_per_rank": [round(r[3], 4) for r in rows],
-                   "bit_identical_to_single_launch_per_rank": [bool(r[4]) for r in rows],
-                   # device timeline of one call, ms from the call's first event on the launch stream, per rank
-                   "timeline_ms_per_rank": [{"exchange_start": round(r[5], 4), "exchange_end": round(r[6], 4),
-                                             "interior_end": round(r[7], 4), "end": round(r[8], 4)} for r in rows],
-                   "halo_hidden_frac_per_rank": [None if r[9] < 0 else round(r[9], 4) for r in rows],
-                   "issue_order_rank0": order, "exchange_stream_priority": {"priority": prio[0], "least": prio[1], "greatest": prio[2]},
-                   "rccl": {"comm_count_per_rank": [int(r[10]) for r in rows], "user_rank_per_rank": [int(r[11]) for r in rows], "version": rc_ver},
-                   "path": "C++: mid_comm_create (ncclCommInitRank via dlopen) + mid_nlm_temporal_sharded "
-                           "(ncclSend/ncclRecv in one group on the highest-priority exchange stream, interior launches meanwhile)"}
+            nat, strong = native_temporal_report(rows, n_seq, world, rehearse, order, prio, rc_ver,
+                                                 [c for _, c in sharding.partition(n_seq, world)])
             also["temporal_nlm_k2_native"] = nat
-            # The sharded path at the top level of the line (the headline above is replicas: weak scaling of independent batches):
-            # BASELINE configs[4] -- ONE 64-frame 1080p sequence, temporal +-2 -- split over the ranks; the same job at every N.
-            hid = [x for x in nat["halo_hidden_frac_per_rank"] if x is not None]
-            res["scaling_strong"] = {
-                "workload": "nlm_temporal_k2_64_frames_1080p_hdr (BASELINE configs[4]): one sequence, contiguous frame blocks per rank, halo over RCCL",
-                "metric": "output Mpixel/s (64 x 1920 x 1080 / max-over-ranks seconds per sequence)",
-                "value": nat["Mpixel/s_out"], "unit": "Mpixel/s", "n_gpus": world, "scaling": "strong", "ms_per_sequence": nat["ms_per_sequence"],
-                "frames_per_rank": [c for _, c in sharding.partition(n_seq, world)],
-                "bit_identical_to_single_launch_per_rank": nat["bit_identical_to_single_launch_per_rank"],
-                "bytes_on_the_wire": int(sum(nat["halo_bytes_sent_per_rank"])),
-                "rccl_comm_count": nat["rccl"]["comm_count_per_rank"], "rccl_version": rc_ver,
-                "exchange_ms_per_rank": nat["exchange_ms_per_rank"],
-                "halo_hidden_frac": (round(min(hid), 4) if hid else None),
-                "halo_hidden_frac_per_rank": nat["halo_hidden_frac_per_rank"],
-                "halo_hidden_frac_def": "share of a rank's exchange (first receive posted .. last transfer complete, device timeline) that ran while "
-                                        "its interior launches were still executing: (min(exchange_end, interior_end) - exchange_start) / "
-                                        "(exchange_end - exchange_start); the value is the worst rank's; null with one rank (nothing is exchanged)",
-                "hardware_status": ("measured in this run" if world > 1 and not rehearse else
-                                    "one rank: no exchange took place -- the N >= 2 figures are unmeasured on hardware until a multi-GPU run"),
-            }
+            res["scaling_strong"] = strong
 
         guarded("temporal_native", extra_temporal_native)
 

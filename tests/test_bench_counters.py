@@ -92,3 +92,28 @@ def test_configs0_image_of_the_cpu_legs_is_the_stated_one():
     img = bench.synth_c1()
     assert img.shape == (512, 512, 4) and img.dtype.name == "uint8" and (img[..., 3] == 255).all()
     assert (bench.synth_c1() == img).all() and img[..., :3].std() > 20                        # seeded; gradient + discs + noise
+
+
+def test_the_sharded_paths_report_is_assembled_for_worlds_this_pool_cannot_run():
+    """bench.py's `scaling_strong` / `also.temporal_nlm_k2_native` for N > 1 come from rows gathered over the ranks; the assembly is a
+    pure function so that its N = 2 and N = 8 forms are exercised here (the driver's multi-GPU run is the first to execute them on
+    hardware): worst-rank halo_hidden_frac, bytes on the wire, per-rank lists of the right length, JSON-serialisable."""
+    import bench
+    for world in (2, 8):
+        frames = [64 // world] * world
+        rows = []
+        for r in range(world):
+            edge = r in (0, world - 1)
+            recv = (2 if edge else 4) * bench.NPIX * 16
+            rows.append([0.020 + 0.001 * r, float(recv), float(recv), 0.45, 1.0, 0.02, 0.47, 9.0 + r, 19.0, 1.0 if r else 0.8, float(world), float(r)])
+        nat, strong = bench.native_temporal_report(rows, 64, world, False, "XIWBB", (-1, 1, -1), 22606, frames)
+        json.dumps({"a": nat, "b": strong})
+        assert strong["n_gpus"] == world and strong["scaling"] == "strong" and strong["frames_per_rank"] == frames
+        assert strong["value"] == round(64 * bench.NPIX / 1e6 / (0.020 + 0.001 * (world - 1)), 1)            # max over ranks sets the time
+        assert strong["halo_hidden_frac"] == 0.8 and len(strong["halo_hidden_frac_per_rank"]) == world       # the worst rank's
+        assert strong["bytes_on_the_wire"] == sum(int(r[2]) for r in rows) == (2 * (world - 1)) * 2 * bench.NPIX * 16
+        assert strong["rccl_comm_count"] == [world] * world and strong["hardware_status"] == "measured in this run"
+        assert all(strong["bit_identical_to_single_launch_per_rank"]) and nat["rccl"]["user_rank_per_rank"] == list(range(world))
+        assert nat["timeline_ms_per_rank"][1] == {"exchange_start": 0.02, "exchange_end": 0.47, "interior_end": 10.0, "end": 19.0}
+    nat, strong = bench.native_temporal_report([[0.14, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 140.0, 140.0, -1.0, 1.0, 0.0]], 64, 1, False, "I", (-1, 1, -1), 22606, [64])
+    assert strong["halo_hidden_frac"] is None and "unmeasured on hardware" in strong["hardware_status"] and strong["bytes_on_the_wire"] == 0

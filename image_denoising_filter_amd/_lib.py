@@ -61,6 +61,7 @@ _SIGNATURES = {
     "mid_ctx_release_cached": (ctypes.c_int, [_P]),
     "mid_last_error": (ctypes.c_char_p, []),
     "mid_version": (ctypes.c_int, []),
+    "mid_ctx_stream_priorities": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mid_device_name": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),
     "mid_alloc": (ctypes.c_int, [_P, ctypes.c_size_t, c_void_pp]),
     "mid_free": (ctypes.c_int, [_P, _P]),
@@ -92,6 +93,9 @@ _SIGNATURES = {
                                                  ctypes.POINTER(ctypes.c_float)]),
     "mid_nlm_multiframe": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), _P, c_void_pp, ctypes.c_int, _P, ctypes.c_int,
                                           ctypes.POINTER(ctypes.c_float)]),
+    "mid_pipe_last_timeline": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int),
+                                              ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float),
+                                              ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mid_shard_block": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mid_shard_halo_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),

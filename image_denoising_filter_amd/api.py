@@ -319,6 +319,17 @@ class Context:
                      (ctypes.c_void_p * count)(*hout[:count]), 1 if overlap else 0, t), "mid_sequence_nlm_range")
         return tuple(t)
 
+    def pipe_last_timeline(self, cap=4096):
+        """mid_pipe_last_timeline: the device timeline of this context's last mid_sequence_nlm* call, from its own events.
+        Returns (uploads, outputs): uploads = [(frame, start_ms, end_ms)], outputs = [(frame, kernel_start, kernel_end,
+        download_start, download_end)], ms from the start of the call's first upload."""
+        up, out = (ctypes.c_float * (2 * cap))(), (ctypes.c_float * (4 * cap))()
+        nu, fu, no, fo = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(lib.mid_pipe_last_timeline(self.handle, cap, up, ctypes.byref(nu), ctypes.byref(fu), out, ctypes.byref(no),
+                                          ctypes.byref(fo)), "mid_pipe_last_timeline")
+        return ([(fu.value + i, up[2 * i], up[2 * i + 1]) for i in range(nu.value)],
+                [(fo.value + j, out[4 * j], out[4 * j + 1], out[4 * j + 2], out[4 * j + 3]) for j in range(no.value)])
+
     def sequence_nlm(self, frames, k=2, overlap=True, hparam=0.5, search=(-7, 7), patch=(-3, 3), pinned=True,
                      first=0, count=None, out_u8=False, pinned_out=True):
         """Host frames in, host frames out through the overlapped pipeline (mid_sequence_nlm_range[_u8]).

@@ -1,7 +1,7 @@
 // capi.cpp -- context, error, memory and timer entry points of libmi_denoise.so.
 // Replaces the Vulkan bootstrap and buffer factories of the reference
 // (src/vk_utils.cpp:13-305, src/main.cpp:247-401) with plain HIP: a context is a device
-// plus its streams (compute, a second compute stream for the frame pipeline, upload, download).
+// plus its four streams (compute, a second compute stream for the frame pipeline, upload, download).
 #include "common.hpp"
 
 namespace mid {
@@ -53,10 +53,23 @@ extern "C" int mid_ctx_create(int device, mid_ctx **out)
     c->lds_max = (int)prop.sharedMemPerBlockOptin > 0 ? (int)prop.sharedMemPerBlockOptin : (int)prop.sharedMemPerBlock;
     if (c->lds_max < 160 * 1024 && (int)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024) c->lds_max = 160 * 1024;
     snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+    // Streams and hardware queues.  The HIP runtime maps a process's streams onto at most 4 hardware queues per priority level
+    // (GPU_MAX_HW_QUEUES), in creation order, a fifth stream sharing the queue of an earlier one; packets of one hardware queue
+    // run in order, so two streams that share a queue and both carry waits hold each other back.  Measured on the frame pipeline
+    // (64 x 1080p RGBA32F host to host, profiles/r06_pipeline_stream_placement.txt): the four streams created together here,
+    // before the process has others: 2858-2868 Mpixel/s; the three pipeline streams created later, by the first pipeline call,
+    // so that upload and download landed on ONE queue: 1681; the same late creation with 8 queues per level: 2395-2412; with the
+    // copy streams in the high-priority pool: 2527-2564.  Hence: all four are created here, back to back, and the two copy
+    // streams -- DMA commands and waits, no workgroups of ours -- at the device's highest priority, which keeps them out of the
+    // pool the caller's streams and the kernel streams live in (2849-2856, and 4107-4125 against 4056-4069 for RGBA8 frames).
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+    c->copy_priority = greatest;
     if (hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->compute2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->upload, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->download, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithPriority(&c->upload, hipStreamNonBlocking, greatest) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->download, hipStreamNonBlocking, greatest) != hipSuccess) {
+        for (hipStream_t s : {c->compute, c->compute2, c->upload, c->download}) if (s) (void)hipStreamDestroy(s);
         delete c;
         return set_error(MID_ERR_HIP, "ctx_create: stream creation failed");
     }
@@ -68,16 +81,10 @@ extern "C" void mid_ctx_destroy(mid_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->compute);
-    (void)hipStreamSynchronize(ctx->compute2);
-    (void)hipStreamSynchronize(ctx->upload);
-    (void)hipStreamSynchronize(ctx->download);
+    for (hipStream_t s : {ctx->compute, ctx->compute2, ctx->upload, ctx->download}) (void)hipStreamSynchronize(s);
     pipe_cache_release(ctx);
     bounce_release(ctx);
-    (void)hipStreamDestroy(ctx->compute);
-    (void)hipStreamDestroy(ctx->compute2);
-    (void)hipStreamDestroy(ctx->upload);
-    (void)hipStreamDestroy(ctx->download);
+    for (hipStream_t s : {ctx->compute, ctx->compute2, ctx->upload, ctx->download}) (void)hipStreamDestroy(s);
     delete ctx;
 }
 
@@ -88,6 +95,17 @@ extern "C" int mid_ctx_release_cached(mid_ctx *ctx)
     std::lock_guard<std::mutex> lock(ctx->pipe.mu);       // (a pipeline call in flight on another thread finishes first)
     pipe_cache_release(ctx);
     bounce_release(ctx);                                   // the two page-locked bounce sets of csrc/hostcopy.cpp (32 MiB)
+    return MID_OK;
+}
+
+extern "C" int mid_ctx_stream_priorities(mid_ctx *ctx, int priority[4], int *least, int *greatest)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(priority && least && greatest, "ctx_stream_priorities: NULL argument");
+    MID_HIP(hipDeviceGetStreamPriorityRange(least, greatest));
+    hipStream_t s[4] = {ctx->compute, ctx->compute2, ctx->upload, ctx->download};
+    for (int i = 0; i < 4; ++i) MID_HIP(hipStreamGetPriority(s[i], &priority[i]));
     return MID_OK;
 }
 

@@ -12,11 +12,13 @@
 // Device buffers and events of the frame pipeline (csrc/pipeline.cpp), kept from call to call so that a steady stream of
 // sequences pays for hipMalloc / hipEventCreate once: grown on demand, released by mid_ctx_release_cached and mid_ctx_destroy.
 struct mid_pipe_set { std::vector<void *> p; size_t bytes = 0; };
+struct mid_pipe_last { int n_up = 0, nb = 0, f_lo = 0, first = 0, batch = 1; bool direct = false; };   // event layout of the last mid_sequence_nlm* call
 struct mid_pipe_cache {
     std::mutex mu;                      // one pipeline call per context at a time: the calls share the context's four streams
     mid_pipe_set ring, out;             // mid_sequence_nlm*: uploaded frames (2k + 4), output slots (4)
     mid_pipe_set target, slots, weights, result;   // mid_nlm_multiframe
     std::vector<hipEvent_t> ev;
+    mid_pipe_last last;                 // mid_pipe_last_timeline reads the events of the last call back
 };
 
 // Page-locked bounce buffers for host memory the caller did NOT pin (csrc/hostcopy.cpp): two halves used alternately, each
@@ -32,10 +34,12 @@ struct mid_bounce {
 
 struct mid_ctx {
     int device;
-    hipStream_t compute;   // default stream for kernels
-    hipStream_t compute2;  // second kernel stream of the frame pipeline (consecutive frames alternate)
-    hipStream_t upload;    // H2D stream of the frame pipeline
-    hipStream_t download;  // D2H stream of the frame pipeline
+    // The four streams are created together, in this order, by mid_ctx_create (capi.cpp explains why and at which priorities).
+    hipStream_t compute = nullptr;   // default stream for kernels
+    hipStream_t compute2 = nullptr;  // second kernel stream of the frame pipeline (consecutive frames alternate)
+    hipStream_t upload = nullptr;    // H2D stream of the frame pipeline    -- device's highest stream priority
+    hipStream_t download = nullptr;  // D2H stream of the frame pipeline    -- device's highest stream priority
+    int copy_priority = 0;           // what upload / download were created with
     int lds_max;           // max dynamic LDS per workgroup (bytes)
     int cu_count;
     char name[128];

@@ -7,11 +7,13 @@
 //
 //   upload   : hipMemcpyAsync host frame f -> device ring slot f % RING
 //   compute  : temporal NLM of output frame t over ring slots t-k..t+k (two kernel streams, frames alternate)
-//   download : hipMemcpyAsync device out slot t % 2 -> host
+//   download : hipMemcpyAsync device out slot t % 4 -> host   (RGBA32F outputs, and RGBA8 outputs in pageable memory)
+//              RGBA8 outputs in page-locked memory have NO download stage: the kernel's epilogue stores the packed pixels
+//              straight into the caller's buffer (4 B per pixel = 17-19 GB/s at the kernel's frame rate, a third of the link)
 //
 // joined only by events: compute(t) waits for upload(t+k); upload(f) waits for the last
 // compute that still reads the slot it overwrites; download(t) waits for compute(t);
-// compute(t) waits for download(t-4) before reusing an output slot.  One output frame per launch
+// compute(t) waits for download(t-4) before reusing an output slot (no slots and no such wait for direct RGBA8 outputs).  One output frame per launch
 // (B = 1 below; coarser batches were measured and lose overlap); the ring holds 2k+4 frames and
 // there are four output slots, so uploads run up to three frames ahead of the kernel and
 // downloads up to three behind: the stages are decoupled and the slowest one (measured: the
@@ -37,6 +39,7 @@ using namespace mid;
 
 namespace {
 
+
 // `n` device buffers of at least `bytes` each from the context's cache.  Every pipeline call ends with all four streams
 // synchronised, so whatever the cache holds is idle when the next call (serialised by pipe.mu) resizes it.
 // Shrink rule: buffers MORE than four times larger than this call needs are given back and reallocated at the size needed (a caller
@@ -58,6 +61,7 @@ int reserve_events(mid_pipe_cache &c, size_t n)
     while (c.ev.size() < n) { hipEvent_t e = nullptr; MID_HIP(hipEventCreate(&e)); c.ev.push_back(e); }
     return MID_OK;
 }
+
 
 // A pipeline call that returns early (an error half way) must still leave the context's streams idle: the cached buffers its
 // queued work reads and writes belong to the next call the moment this one returns.
@@ -84,6 +88,7 @@ void mid::pipe_cache_release(mid_ctx *ctx)
     }
     for (hipEvent_t e : c.ev) (void)hipEventDestroy(e);
     c.ev.clear();
+    c.last = mid_pipe_last{};
 }
 
 // Outputs [first, first+count) of an n-frame host sequence; frames outside that range are only
@@ -122,10 +127,25 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
     Range call_range("mid_sequence_nlm frames=%d k=%d outputs=[%d,%d)%s", n, k, first, first + count, out_u8 ? " u8" : "");
     std::lock_guard<std::mutex> pipe_lock(ctx->pipe.mu);
     DrainOnExit drain{ctx};
+    // Where do the outputs go?  RGBA8 outputs in page-locked memory are written by the kernel itself (`direct`): a pinned buffer is
+    // mapped into the device's address space, the packed pixel is 4 B, and at the kernel's frame rate that is 17-19 GB/s of posted
+    // writes -- a third of the link -- so the download stage, its output slots and the wait for a free slot disappear.  Measured
+    // on 64 x 1080p (profiles/r06_pipeline_u8_timeline.txt, LABNOTES R6.1): staged through hipMemcpyAsync the runtime's copies
+    // went from 0.19 to 0.67 ms per frame part way into a call and the four output slots then gated every launch (3230-3590
+    // Mpixel/s, 5-10 % spread); direct 4040-4080, spread 1-3 %.  RGBA32F outputs (16 B per pixel: more than the link carries at the
+    // kernel's rate) and pageable outputs keep the staged download.
+    bool out_pinned = true;
+    for (int i = 0; i < count; ++i) out_pinned = out_pinned && host_is_pinned(host_out[i], dl_bytes);
+    bool direct = out_u8 && out_pinned;
+    for (int i = 0; direct && i < count; ++i) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, host_out[i], 0) != hipSuccess || !dp) { (void)hipGetLastError(); direct = false; }
+    }
     mid_pipe_set &dring = ctx->pipe.ring, &dout = ctx->pipe.out;
     if (int rc = reserve(dring, ring, in_bytes)) return rc;
-    if (int rc = reserve(dout, DEPTH * B, dl_bytes)) return rc;
+    if (!direct) { if (int rc = reserve(dout, DEPTH * B, dl_bytes)) return rc; }
     if (int rc = reserve_events(ctx->pipe, 2 * (size_t)n_up + 4 * (size_t)nb)) return rc;
+    ctx->pipe.last = mid_pipe_last{};
     struct Events { hipEvent_t *ev; } up0{ctx->pipe.ev.data()}, up1{up0.ev + n_up}, c0{up1.ev + n_up}, c1{c0.ev + nb}, d0{c1.ev + nb}, d1{d0.ev + nb};
     auto slot = [&](int f) { return dring.p[(f - f_lo) % ring]; };
 
@@ -156,8 +176,6 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
     // finished frames out -- the two memcpy streams overlap (16 x 1080p RGBA32F with pageable frames on both sides: 42.9 ms with
     // both on one thread).  The helper takes batch bi once compute(bi) has been queued; compute(bi) is queued only when the helper
     // has recorded d1[bi-DEPTH] (the output slot is free) -- the event order of the pinned case, kept by two counters.
-    bool out_pinned = true;
-    for (int i = 0; i < count; ++i) out_pinned = out_pinned && host_is_pinned(host_out[i], dl_bytes);
     auto download = [&](int bi) -> int {
         const int b0 = first + bi * B, bn = (first + count - b0) < B ? (first + count - b0) : B;
         Range r("download %d", b0);
@@ -185,8 +203,8 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
             th.join();                   // before DrainOnExit and before anything the download lambda refers to goes away
         }
     } helper;
-    const bool threaded = !out_pinned && overlap;
-    if (threaded) {
+    bool threaded = !out_pinned && overlap;
+    if (threaded) try {
         helper.th = std::thread([&] {
             (void)hipSetDevice(ctx->device);
             for (int bi = 0; bi < nb; ++bi) {
@@ -205,6 +223,8 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
                 if (rc) return;
             }
         });
+    } catch (...) {
+        threaded = false;            // no thread to be had (EAGAIN under a thread limit): the downloads run on the calling thread
     }
     // the helper's error, if any, becomes this thread's error
     auto helper_failed = [&]() -> int {
@@ -229,7 +249,7 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
         // Output slot bi % DEPTH was written by batch bi-DEPTH and is read only by download(bi-DEPTH), which
         // itself waited for c1[bi-DEPTH]: d1[bi-DEPTH] therefore orders both the writer and the only reader of
         // the slot before this batch, whichever kernel stream they ran on.
-        if (bi >= DEPTH) {
+        if (bi >= DEPTH && !direct) {
             if (threaded) {              // d1[bi-DEPTH] must have been RECORDED before a stream can be told to wait for it
                 std::unique_lock<std::mutex> l(helper.mu);
                 helper.cv.wait(l, [&] { return helper.stop || helper.done >= bi - DEPTH; });
@@ -242,7 +262,10 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
         const void *tbl[kMaxFrames];
         for (int f = lo; f <= need; ++f) tbl[f - lo] = slot(f);
         mid_pixel *o[kMaxFrames];
-        for (int i = 0; i < bn; ++i) o[i] = (mid_pixel *)dout.p[(bi % DEPTH) * B + i];
+        for (int i = 0; i < bn; ++i) {
+            if (direct) MID_HIP(hipHostGetDevicePointer((void **)&o[i], host_out[b0 - first + i], 0));
+            else o[i] = (mid_pixel *)dout.p[(bi % DEPTH) * B + i];
+        }
         {
             Range nlm_range("nlm %d", b0);
             MID_HIP(hipEventRecord(c0.ev[bi], cs));
@@ -254,7 +277,9 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
 
         while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }
 
-        if (threaded) {
+        if (direct) {
+            // nothing to download: the launch wrote the caller's buffer
+        } else if (threaded) {
             { std::lock_guard<std::mutex> l(helper.mu); helper.issued = bi; }
             helper.cv.notify_all();
         } else if (int rc = download(bi)) return rc;
@@ -281,18 +306,49 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
         MID_HIP(hipStreamSynchronize(ctx->download));
     }
     const auto wall1 = std::chrono::steady_clock::now();
+    ctx->pipe.last = {n_up, nb, f_lo, first, B, direct};
 
     if (timings_ms) {
         float kern = 0.f, copy = 0.f, ms = 0.f;
         for (int bi = 0; bi < nb; ++bi) {
             MID_HIP(hipEventElapsedTime(&ms, c0.ev[bi], c1.ev[bi])); kern += ms;
-            MID_HIP(hipEventElapsedTime(&ms, d0.ev[bi], d1.ev[bi])); copy += ms;
+            if (!direct) { MID_HIP(hipEventElapsedTime(&ms, d0.ev[bi], d1.ev[bi])); copy += ms; }
         }
         for (int i = 0; i < n_up; ++i) { MID_HIP(hipEventElapsedTime(&ms, up0.ev[i], up1.ev[i])); copy += ms; }
         timings_ms[0] = std::chrono::duration<float, std::milli>(wall1 - wall0).count();
         timings_ms[1] = kern;
         timings_ms[2] = copy;
     }
+    return MID_OK;
+}
+
+// Device timeline of the context's last mid_sequence_nlm* call, read back from the events the call left in the context's
+// cache (valid until the next pipeline call on this context; no profiler involved, so the call ran at its own pace).
+extern "C" int mid_pipe_last_timeline(mid_ctx *ctx, int cap, float *upload_ms, int *n_uploads, int *first_upload_frame,
+                                      float *output_ms, int *n_outputs, int *first_output_frame)
+{
+    Bind b(ctx, nullptr);
+    if (b.rc) return b.rc;
+    MID_REQUIRE(upload_ms && n_uploads && first_upload_frame && output_ms && n_outputs && first_output_frame && cap >= 0,
+                "pipe_last_timeline: bad argument");
+    std::lock_guard<std::mutex> pipe_lock(ctx->pipe.mu);
+    const mid_pipe_last &L = ctx->pipe.last;
+    MID_REQUIRE(L.n_up > 0, "pipe_last_timeline: no mid_sequence_nlm* call has completed on this context");
+    MID_REQUIRE(cap >= L.n_up && cap >= L.nb, "pipe_last_timeline: cap=%d, need %d uploads and %d outputs", cap, L.n_up, L.nb);
+    MID_REQUIRE(ctx->pipe.ev.size() >= 2 * (size_t)L.n_up + 4 * (size_t)L.nb, "pipe_last_timeline: the event cache was released");
+    hipEvent_t *up0 = ctx->pipe.ev.data(), *up1 = up0 + L.n_up, *c0 = up1 + L.n_up, *c1 = c0 + L.nb, *d0 = c1 + L.nb, *d1 = d0 + L.nb;
+    for (int i = 0; i < L.n_up; ++i) {
+        MID_HIP(hipEventElapsedTime(&upload_ms[2 * i], up0[0], up0[i]));
+        MID_HIP(hipEventElapsedTime(&upload_ms[2 * i + 1], up0[0], up1[i]));
+    }
+    for (int i = 0; i < L.nb; ++i) {
+        MID_HIP(hipEventElapsedTime(&output_ms[4 * i], up0[0], c0[i]));
+        MID_HIP(hipEventElapsedTime(&output_ms[4 * i + 1], up0[0], c1[i]));
+        // direct RGBA8 outputs have no download stage: reported as an empty interval at the end of the launch
+        MID_HIP(hipEventElapsedTime(&output_ms[4 * i + 2], up0[0], L.direct ? c1[i] : d0[i]));
+        MID_HIP(hipEventElapsedTime(&output_ms[4 * i + 3], up0[0], L.direct ? c1[i] : d1[i]));
+    }
+    *n_uploads = L.n_up; *first_upload_frame = L.f_lo; *n_outputs = L.nb; *first_output_frame = L.first;
     return MID_OK;
 }
 
@@ -341,6 +397,7 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
     if (int rc = reserve(dW, 1, npix * sizeof(mid_weightinfo))) return rc;
     if (int rc = reserve(dout, 1, out_bytes)) return rc;
     if (int rc = reserve_events(ctx->pipe, 4 * (size_t)n + 4)) return rc;
+    ctx->pipe.last = mid_pipe_last{};                         // the cached events are about to be re-recorded in another layout
     struct Events { hipEvent_t *ev; } up0{ctx->pipe.ev.data()}, up1{up0.ev + n}, c0{up1.ev + n}, c1{c0.ev + n}, misc{c1.ev + n};
 
     // target + cleared weight buffer (the reference relies on a fresh allocation being zero)
@@ -360,14 +417,19 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
     };
     int next_upload = 0;
     for (int f = 0; f < n; ++f) {
-        // overlap: frames f+1, f+2 ride beside dispatch f (their slots were last read by dispatches already enqueued)
+        while (next_upload <= f) { if (int rc = upload(next_upload++)) return rc; }
+        {
+            Range r("nlm %d", f);
+            MID_HIP(hipStreamWaitEvent(ctx->compute, up1.ev[f], 0));
+            MID_HIP(hipEventRecord(c0.ev[f], ctx->compute));
+            if (int rc = mid_nlm_accum(ctx, p, dtarget.p[0], dslot.p[f % SLOTS], (mid_weightinfo *)dW.p[0], ctx->compute)) return rc;
+            MID_HIP(hipEventRecord(c1.ev[f], ctx->compute));
+        }
+        // overlap: frames f+1, f+2 ride beside dispatch f (their slots were last read by dispatches already enqueued).  They are
+        // started AFTER dispatch f has been queued, as in sequence_impl: a pageable frame blocks the calling thread inside
+        // copy_h2d until its chunks have gone through the bounce buffers, and the device must not sit idle meanwhile.
         const int ahead = overlap ? (f + SLOTS - 1 < n - 1 ? f + SLOTS - 1 : n - 1) : f;
         while (next_upload <= ahead) { if (int rc = upload(next_upload++)) return rc; }
-        Range r("nlm %d", f);
-        MID_HIP(hipStreamWaitEvent(ctx->compute, up1.ev[f], 0));
-        MID_HIP(hipEventRecord(c0.ev[f], ctx->compute));
-        if (int rc = mid_nlm_accum(ctx, p, dtarget.p[0], dslot.p[f % SLOTS], (mid_weightinfo *)dW.p[0], ctx->compute)) return rc;
-        MID_HIP(hipEventRecord(c1.ev[f], ctx->compute));
         if (!overlap) {   // fence after every submit, src/main.cpp:1092
             MID_HIP(hipStreamSynchronize(ctx->compute));
             MID_HIP(hipStreamSynchronize(ctx->upload));

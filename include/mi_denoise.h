@@ -111,6 +111,12 @@ int         mid_ctx_release_cached(mid_ctx *ctx);
 const char *mid_last_error(void);
 int         mid_version(void);
 int         mid_device_name(mid_ctx *ctx, char *buf, size_t buflen);
+/* The context's four streams -- [0] compute (the default for stream = NULL), [1] the frame pipeline's second kernel stream,
+ * [2] its upload and [3] its download stream -- are created together by mid_ctx_create; the two copy streams at the device's
+ * highest stream priority (numerically lowest: `greatest`), so that they never share one of the runtime's hardware queues with
+ * the kernel streams or with the caller's streams (csrc/capi.cpp has the measurements).  Stands where the reference takes its
+ * single queue (vkGetDeviceQueue, src/main.cpp:1335). */
+int         mid_ctx_stream_priorities(mid_ctx *ctx, int priority[4], int *least, int *greatest);
 
 int mid_alloc(mid_ctx *ctx, size_t bytes, void **dptr);              /* CreateWriteOnlyBuffer & co */
 int mid_free(mid_ctx *ctx, void *dptr);
@@ -219,6 +225,15 @@ int mid_sequence_nlm_range(mid_ctx *ctx, const mid_nlm_params *p, const void *co
 int mid_sequence_nlm_range_u8(mid_ctx *ctx, const mid_nlm_params *p, const void *const *host_frames,
                               int n_frames, int k, int first, int count, uint8_t *const *host_out,
                               int overlap, float *timings_ms);
+
+/* Debug export: the DEVICE timeline of this context's last mid_sequence_nlm* call, from the events the call recorded on
+ * its streams (no profiler: the call ran at its own pace).  All times in ms from the start of the call's first upload.
+ * upload_ms[2*i], [2*i+1]: start / end of the upload of frame first_upload_frame + i; output_ms[4*j .. 4*j+3]: kernel
+ * start, kernel end, download start, download end of output frame first_output_frame + j (output j runs on kernel stream
+ * j & 1).  cap = rows either array can hold.  Valid until the next pipeline call or mid_ctx_release_cached on the context.
+ * Stands where the reference prints its per-submit timestamps (src/main.cpp:1095-1101). */
+int mid_pipe_last_timeline(mid_ctx *ctx, int cap, float *upload_ms /* cap x 2 */, int *n_uploads, int *first_upload_frame,
+                           float *output_ms /* cap x 4 */, int *n_outputs, int *first_output_frame);
 
 /* The reference's literal multi-frame mode (src/main.cpp:1539-1606): ONE target, its neighbour frames
  * streamed from the host.  W = sum over frames of one nonlocal.comp dispatch each (target fixed), then

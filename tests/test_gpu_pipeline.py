@@ -176,3 +176,99 @@ def test_pipeline_cache_follows_the_frame_size_down_as_well_as_up(ctx):
     ctx.sequence_nlm([np.clip(f * 255, 0, 255).astype(np.uint8) for f in big], k=1, out_u8=True)
     assert abs(torch.cuda.mem_get_info(0)[0] - free_a) < 16e6       # (no 33 MB buffer was freed or allocated; small runtime pools may move)
     ctx.release_cached()
+
+
+def test_u8_outputs_in_pinned_memory_are_written_by_the_kernel_itself(ctx):
+    """Round 6: RGBA8 outputs in page-locked memory have no download stage -- the launch stores the packed pixels into the
+    caller's buffer (csrc/pipeline.cpp, `direct`).  Same bytes as the staged path (pageable outputs: output slots + bounce
+    buffers), as one launch + mid_pack_u8, for more frames than the staged path has slots, for caller-registered arrays, and
+    a single pageable output sends the whole call down the staged path."""
+    import image_denoising_filter_amd as mid
+    from conftest import synth_ldr
+    rng = np.random.default_rng(66)
+    n, h, w = 11, 130, 200
+    frames = [synth_ldr(rng, h, w) for _ in range(n)]
+    for k in (0, 2):
+        want = [ctx.pack_u8(o) for o in ctx.nlm_temporal(frames, k=k)]
+        direct, _ = ctx.sequence_nlm(frames, k=k, out_u8=True)                        # PinnedFrames outputs
+        staged, _ = ctx.sequence_nlm(frames, k=k, out_u8=True, pinned_out=False)      # NumPy outputs: pageable
+        serial, _ = ctx.sequence_nlm(frames, k=k, out_u8=True, overlap=False)
+        for a, b, c, d in zip(want, direct, staged, serial):
+            assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d)
+        up, out = ctx.pipe_last_timeline()                                             # of the serial (direct) call
+        assert all(o[3] == o[2] == o[4] for o in out)                                  # no download interval
+    # outputs that live in the caller's own arrays, pinned in place
+    outs = [np.full((h, w, 4), 7, np.uint8) for _ in range(n)]
+    pin = mid.PinnedFrames(ctx, frames)
+    for o in outs:
+        assert mid.lib.mid_host_register(ctx.handle, o.ctypes.data, o.nbytes) == 0
+    try:
+        ctx.sequence_nlm_pinned(pin.ptrs, [o.ctypes.data for o in outs], w, h, mid.FMT_RGBA8, k=2, out_u8=True)
+        assert all(np.array_equal(a, b) for a, b in zip(outs, want))
+    finally:
+        for o in outs:
+            assert mid.lib.mid_host_unregister(ctx.handle, o.ctypes.data) == 0
+    # one pageable output among pinned ones: still right (the call takes the staged path as a whole)
+    hout = mid.PinnedFrames(ctx, n, h * w * 4)
+    odd = np.zeros((h, w, 4), np.uint8)
+    ptrs = list(hout.ptrs)
+    ptrs[4] = odd.ctypes.data
+    try:
+        ctx.sequence_nlm_pinned(pin.ptrs, ptrs, w, h, mid.FMT_RGBA8, k=2, out_u8=True)
+        got = [odd if i == 4 else hout.array(i, (h, w, 4), np.uint8) for i in range(n)]
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+        up, out = ctx.pipe_last_timeline()
+        assert all(o[4] > o[3] >= o[2] for o in out)                                   # staged: a download after each launch
+    finally:
+        hout.free(); pin.free()
+
+
+def test_pipe_last_timeline_reports_the_calls_own_events(ctx):
+    """mid_pipe_last_timeline: per-frame device times of the last mid_sequence_nlm* call, ordered the way the event graph orders
+    them; refused with a message when there is nothing to report or the arrays are too small."""
+    import ctypes
+    import image_denoising_filter_amd as mid
+    rng = np.random.default_rng(67)
+    n, k, first, count = 12, 1, 2, 8
+    frames = [synth_hdr(rng, 96, 160) * 0.3 for _ in range(n)]
+    fresh = mid.Context(0)
+    try:
+        with pytest.raises(mid.MidError, match="no mid_sequence_nlm"):
+            fresh.pipe_last_timeline()
+        fresh.sequence_nlm(frames, k=k, first=first, count=count)
+        up, out = fresh.pipe_last_timeline()
+        assert [u[0] for u in up] == list(range(first - k, first + count + k)) and [o[0] for o in out] == list(range(first, first + count))
+        assert up[0][1] == 0.0 and all(b >= a for _, a, b in up) and all(up[i + 1][1] >= up[i][2] for i in range(len(up) - 1))
+        up_end = {f: e for f, _, e in up}
+        for j, (t, c0, c1, d0, d1) in enumerate(out):
+            assert c0 >= up_end[t + k] and c1 > c0 and d0 >= c1 and d1 > d0          # RGBA32F outputs: staged download
+            if j >= 2:
+                assert c0 >= out[j - 2][2]                                             # stream order on its kernel stream
+            if j >= 4:
+                assert c0 >= out[j - 4][4]                                             # output slot reuse
+        nu, fu, no, fo = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        small = (ctypes.c_float * 8)()
+        rc = mid.lib.mid_pipe_last_timeline(fresh.handle, 2, small, ctypes.byref(nu), ctypes.byref(fu), small, ctypes.byref(no), ctypes.byref(fo))
+        assert rc == 1 and b"cap=2" in mid.lib.mid_last_error()
+        assert mid.lib.mid_pipe_last_timeline(fresh.handle, 2, None, None, None, None, None, None) == 1
+        fresh.nlm_multiframe(frames[0], frames[:3])                                    # re-records the cached events in another layout
+        with pytest.raises(mid.MidError):
+            fresh.pipe_last_timeline()
+        fresh.sequence_nlm(frames[:3], k=0)
+        fresh.release_cached()
+        with pytest.raises(mid.MidError):
+            fresh.pipe_last_timeline()
+    finally:
+        fresh.close()
+
+
+def test_copy_streams_live_in_the_high_priority_pool(ctx):
+    """mid_ctx_stream_priorities: the context's two kernel streams at the default priority, its two copy streams at the device's
+    highest (csrc/capi.cpp: they must not share a hardware queue with each other, the kernel streams or the caller's streams)."""
+    import ctypes
+    import image_denoising_filter_amd as mid
+    pr, least, greatest = (ctypes.c_int * 4)(), ctypes.c_int(), ctypes.c_int()
+    assert mid.lib.mid_ctx_stream_priorities(ctx.handle, pr, ctypes.byref(least), ctypes.byref(greatest)) == 0
+    assert greatest.value < least.value                                                 # numerically lower = higher
+    assert list(pr) == [0, 0, greatest.value, greatest.value]
+    assert mid.lib.mid_ctx_stream_priorities(ctx.handle, None, None, None) == 1

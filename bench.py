@@ -281,6 +281,12 @@ def cpu_baseline(workload="nlm"):
         out["reference_cpu_path"] = _cpu_reference_bilateral(oracle)
     except Exception as e:  # noqa: BLE001 - the secondary figure must not cost the primary one
         out["reference_cpu_path"] = {"value": None, "sample": f"failed: {e}"}
+    # The reference's OWN CPU path, where cpu_baseline is read: value/kind above are the port of the headline workload (the
+    # reference has no CPU NLM); `reference` is the loop the reference does ship (bilateral, src/main.cpp:1819-1865), compiled
+    # from its sources -- another filter than `value`'s, so it sits beside the port, not in its place.
+    ref = out["reference_cpu_path"]
+    out["reference"] = {kk: ref.get(kk) for kk in ("value", "unit", "cores", "kind", "sample")}
+    out["reference"]["workload"] = "bilateral r=10 (RunOnCPU's own window), not the NLM workload of `value`; all legs under reference_cpu_path"
     return out
 
 
@@ -599,7 +605,7 @@ def main():
                    "parallelism": f"frame-sharded x{world}, no data-path collective",
                    **({"process_group": process_group} if process_group else {})},
         "roofline": {
-            "bound": "mfma", "bound_actual": "valu", "achieved": round(flop_px * px_per_launch / avg_launch_s / 1e12, 3),
+            "bound": "mfma", "bound_contract_side": "compute (the enum is hbm | mfma; the kernel issues no MFMA: bound_actual)", "bound_actual": "valu", "achieved": round(flop_px * px_per_launch / avg_launch_s / 1e12, 3),
             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop_px * px_per_launch / avg_launch_s / 1e12 / PEAK_FP32_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
@@ -913,7 +919,7 @@ def main():
             finally:
                 up.free(); down.free(); d_up.free(); d_down.free()
 
-        def pipeline_passes(fr, out_u8, passes=4):
+        def pipeline_passes(fr, out_u8, passes=4, k=0):
             """The pipeline as a C caller sees it: frames already in pinned memory, a clock around the C call (and the call's own
             timings_ms[0] beside it -- since round 4 that covers the whole call too).  First call = the context's cache empty
             (mid_ctx_release_cached before it): ring, output slots and events are allocated inside the call.  Steady state =
@@ -932,7 +938,7 @@ def main():
             try:
                 def call():
                     t0 = time.perf_counter()
-                    inside = ctx.sequence_nlm_pinned(hin, hout.ptrs, w_, h_, fmt, k=0, overlap=True, search=SEARCH, patch=PATCH, out_u8=out_u8)
+                    inside = ctx.sequence_nlm_pinned(hin, hout.ptrs, w_, h_, fmt, k=k, overlap=True, search=SEARCH, patch=PATCH, out_u8=out_u8)
                     return (time.perf_counter() - t0) * 1e3, inside
                 ctx.release_cached()
                 first_ms, first_in = call()
@@ -965,7 +971,11 @@ def main():
                 # the reference's LDR path: RGBA8 frames in, RGBA8 frames out (u8 conversion on the device)
                 lf = [np.clip(f * 64.0, 0, 255).astype(np.uint8) for f in hf]
                 r8 = pipeline_passes(lf, out_u8=True)
-                r8["note"] = "host RGBA8 frames in, RGBA8 frames out (mid_sequence_nlm_range_u8): 4 B/px each way, kernel-bound"
+                r8["note"] = ("host RGBA8 frames in, RGBA8 frames out (mid_sequence_nlm_range_u8), 4 B/px each way.  Round 6: the outputs are in "
+                              "page-locked memory, so the kernel's epilogue stores them straight into the caller's buffers -- no download stage "
+                              "(copy_ms = uploads only).  Bound by the kernel streams: two co-running single-frame launches, kernel_ms / 2 of "
+                              "call_ms busy per stream; the staged download it replaced was bound by the runtime's device-to-host copies turning "
+                              "3.5x slower part way into a 64-frame call (profiles/r06_pipeline_u8_timeline.txt, LABNOTES R6.1)")
                 r8["pcie_frac"] = round(r8["Mpixel/s_overlap"] * 4e6 / 1e9 / min(ceil32["h2d_GBs"], ceil32["d2h_GBs"]), 4)
                 also["pipeline_pcie_inclusive_ldr"] = r8
 
@@ -986,6 +996,26 @@ def main():
                 also["pipeline_pcie_inclusive_64"] = r
 
         guarded("pipeline_long", extra_pipeline_long)
+
+        def extra_pipeline_k2():
+            if rank == 0 and world == 1:
+                # BASELINE configs[4] host -> host on ONE GPU: mid_sequence_nlm with k = 2 over a 64-frame 1080p RGBA32F sequence in
+                # pinned memory -- the reference's "async copy overlap" mode (RecordCommandsOfOverlappingNLM, src/main.cpp:889-989,
+                # loop :1539-1573) with the explicit +-2 window.  Five frame pairs per output make it kernel-bound: the copies (16 B/px
+                # each way) hide behind the launches; the figure to hold it against is temporal_nlm_k2 (frames resident in HBM).
+                hf = [f.cpu().numpy() for f in frames[:XF]]
+                r = pipeline_passes([hf[i % len(hf)] for i in range(SEQ_FRAMES)], out_u8=False, passes=2, k=2)
+                r = {("out-" + kk if kk.startswith("Mpixel/s") else kk): v for kk, v in r.items()}
+                res_t = also.get("temporal_nlm_k2", {}).get("Mpixel/s_out")
+                if res_t:
+                    r["ratio_to_temporal_nlm_k2"] = round(r["out-Mpixel/s_overlap"] / res_t, 4)
+                r["k"] = 2
+                r["note"] = ("64 x 1080p RGBA32F host frames in pinned memory -> H2D, temporal NLM +-2 (one output per launch, two alternating "
+                             "kernel streams, ring of 2k+4 device frames), D2H; output-Mpixel/s; kernel_ms = sum over both kernel streams, "
+                             "copy_ms = sum of uploads and downloads; ratio_to_temporal_nlm_k2 = against the same sequence resident in HBM")
+                also["pipeline_k2_64"] = r
+
+        guarded("pipeline_k2", extra_pipeline_k2)
 
     res["also"] = also
 

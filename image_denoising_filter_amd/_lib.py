@@ -110,6 +110,7 @@ _SIGNATURES = {
     "mid_comm_reserve": (ctypes.c_int, [_P, ctypes.c_size_t, ctypes.c_int]),
     "mid_comm_rank": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mid_comm_loopback": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P]),
+    "mid_comm_last_loopback": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_float)]),
     "mid_nlm_temporal_sharded": (ctypes.c_int, [_P, ctypes.POINTER(NlmParams), c_void_pp, ctypes.c_int, ctypes.c_int, c_void_pp, _P]),
     "mid_range_push": (ctypes.c_int, [ctypes.c_char_p]),
     "mid_range_pop": (ctypes.c_int, []),

@@ -472,6 +472,13 @@ class Comm:
     def loopback(self, src_ptr, dst_ptr, nbytes, stream=None):
         _check(lib.mid_comm_loopback(self.handle, src_ptr, dst_ptr, nbytes, stream), "mid_comm_loopback")
 
+    def last_loopback(self):
+        """(start ms, end ms) of the last loopback's send+receive group on the exchange stream, from the moment the caller's
+        stream reached the call (mid_comm_last_loopback; waits for it)."""
+        t = (ctypes.c_float * 2)()
+        _check(lib.mid_comm_last_loopback(self.handle, t), "mid_comm_last_loopback")
+        return float(t[0]), float(t[1])
+
     def nlm_temporal_sharded_dev(self, block_ptrs, out_ptrs, w, h, n_frames, k, hparam, search, patch, fmt, stream=None):
         """This rank's block (device pointers, in order) -> its outputs; halo over RCCL, interior launches meanwhile."""
         _, count = shard_block(n_frames, self.world, self.rank)

@@ -197,6 +197,8 @@ struct mid_comm {
     hipStream_t xs = nullptr;               // exchange stream (highest priority the device offers: see comm_finish_create)
     int xs_priority = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr, x0 = nullptr;
+    hipEvent_t l0 = nullptr, l1 = nullptr, lq = nullptr;   // mid_comm_loopback's own events: queued (caller's stream), start and end (exchange stream)
+    bool have_loop = false;
     hipStream_t bs = nullptr;               // boundary stream: the launches that wait for the halo run here, beside the interior launches' tail
     hipEvent_t b1 = nullptr;                // end of the boundary launches on bs; the caller's stream waits for it before `done`
     bool bs_used = false;                   // this call queued something on bs (the join is then owed, also on an error path)
@@ -229,6 +231,9 @@ static int comm_finish_create(mid_comm *c)
     MID_HIP(hipEventCreate(&c->e0));
     MID_HIP(hipEventCreate(&c->e1));
     MID_HIP(hipEventCreate(&c->x0));
+    MID_HIP(hipEventCreate(&c->l0));
+    MID_HIP(hipEventCreate(&c->l1));
+    MID_HIP(hipEventCreate(&c->lq));
     MID_HIP(hipEventCreate(&c->i1));
     MID_HIP(hipEventCreate(&c->done));
     MID_HIP(hipStreamCreateWithFlags(&c->bs, hipStreamNonBlocking));
@@ -352,6 +357,7 @@ extern "C" int mid_comm_destroy(mid_comm *c)
     if (c->e0) (void)hipEventDestroy(c->e0);
     if (c->e1) (void)hipEventDestroy(c->e1);
     if (c->x0) (void)hipEventDestroy(c->x0);
+    for (hipEvent_t e : {c->l0, c->l1, c->lq}) if (e) (void)hipEventDestroy(e);
     if (c->i1) (void)hipEventDestroy(c->i1);
     if (c->b1) (void)hipEventDestroy(c->b1);
     if (c->bs) { (void)hipStreamSynchronize(c->bs); (void)hipStreamDestroy(c->bs); }
@@ -391,22 +397,42 @@ extern "C" int mid_comm_rank(mid_comm *c, int *rank, int *world)
 
 // ncclSend + ncclRecv addressed to this very rank inside one group on the exchange stream: the halo exchange's call
 // pattern minus the wire -- what can be exercised on a one-GPU box (tests, smoke); also a cheap liveness probe of a comm.
+// It records its OWN events (lq on the caller's stream, l0/l1 around the group on the exchange stream): the timeline of the
+// last sharded call (e0/x0/e1/i1/done) stays that call's, whatever is looped back afterwards.
 extern "C" int mid_comm_loopback(mid_comm *c, const void *src, void *dst, size_t bytes, void *stream)
 {
     MID_REQUIRE(c && src && dst && bytes > 0, "comm_loopback: bad argument");
     MID_REQUIRE(!c->aborted, "comm_loopback: the communicator was aborted");
     Bind b(c->ctx, stream);
     if (b.rc) return b.rc;
-    MID_HIP(hipEventRecord(c->e0, b.s));
-    MID_HIP(hipStreamWaitEvent(c->xs, c->e0, 0));
+    c->have_loop = false;
+    MID_HIP(hipEventRecord(c->lq, b.s));
+    MID_HIP(hipStreamWaitEvent(c->xs, c->lq, 0));
+    MID_HIP(hipEventRecord(c->l0, c->xs));
     MID_NCCL(rccl().GroupStart());
     ncclResult_t r1 = rccl().Recv(dst, bytes, ncclUint8, c->rank, c->comm, c->xs);
     ncclResult_t r2 = rccl().Send(src, bytes, ncclUint8, c->rank, c->comm, c->xs);
     ncclResult_t r3 = rccl().GroupEnd();
     if (r1 != ncclSuccess || r2 != ncclSuccess || r3 != ncclSuccess)
         return set_error(MID_ERR_HIP, "comm_loopback: ncclRecv/ncclSend/ncclGroupEnd: %s / %s / %s", rccl().GetErrorString(r1), rccl().GetErrorString(r2), rccl().GetErrorString(r3));
-    MID_HIP(hipEventRecord(c->e1, c->xs));
-    MID_HIP(hipStreamWaitEvent(b.s, c->e1, 0));
+    MID_HIP(hipEventRecord(c->l1, c->xs));
+    MID_HIP(hipStreamWaitEvent(b.s, c->l1, 0));
+    c->have_loop = true;
+    return MID_OK;
+}
+
+// (waits for it) the last loopback on the device's clock, ms from the moment the caller's stream reached the call:
+// t[0] start, t[1] end of the send+receive group on the exchange stream.
+extern "C" int mid_comm_last_loopback(mid_comm *c, float t_ms[2])
+{
+    MID_REQUIRE(c && t_ms, "comm_last_loopback: NULL argument");
+    t_ms[0] = t_ms[1] = 0.f;
+    MID_REQUIRE(c->have_loop, "comm_last_loopback: no mid_comm_loopback has been queued on this communicator");
+    Bind b(c->ctx, nullptr);
+    if (b.rc) return b.rc;
+    MID_HIP(hipEventSynchronize(c->l1));
+    MID_HIP(hipEventElapsedTime(&t_ms[0], c->lq, c->l0));
+    MID_HIP(hipEventElapsedTime(&t_ms[1], c->lq, c->l1));
     return MID_OK;
 }
 
@@ -459,8 +485,12 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
                     (void)hipStreamSynchronize(c->bs);             // (a broken device: fall back to a host-side join)
                 c->bs_used = false;
             }
+            // `done` is what the next call's stream rule and reserve_halo's "may the retired buffers go" test: it must stand
+            // behind THIS call's work.  If it cannot be recorded (a broken device), a stale `done` of an older call would answer
+            // for this one -- so wait the stream out on the host instead and leave no call to be asked about.
             c->have_done = hipEventRecord(c->done, s) == hipSuccess;
-            c->last_stream = s; c->has_last = true;
+            c->last_stream = s; c->has_last = c->have_done;
+            if (!c->have_done) (void)hipStreamSynchronize(s);
         }
     } finish{c, b.s};
 

@@ -279,7 +279,9 @@ int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const void *host_t
  *   call allocates (optional; otherwise they are allocated on first use and retired, not freed, when the frame size grows).
  * mid_comm_abort: ncclCommAbort -- tears the rank's connections down without waiting for outstanding operations; the
  *   handle then only accepts mid_comm_destroy.
- * mid_comm_loopback: a send+receive addressed to this very rank (the exchange's call pattern without the wire).
+ * mid_comm_loopback: a send+receive addressed to this very rank (the exchange's call pattern without the wire), asynchronous on
+ *   `stream`; mid_comm_last_loopback: (waits for it) t[0] start / t[1] end of that group on the exchange stream, in ms from the
+ *   moment `stream` reached the call.  Its events are its own: the last sharded call's timeline is not disturbed.
  * mid_comm_last_exchange: bytes received/sent by the last sharded call and (waits for it) the exchange's duration.
  * mid_comm_last_timeline: (waits for the call) its device timeline in ms from the call's first event on the caller's stream:
  *   t[0] exchange start, t[1] exchange end (both 0 when nothing was exchanged), t[2] end of the interior launches, t[3] end of
@@ -304,6 +306,7 @@ int mid_comm_abort(mid_comm *comm);
 int mid_comm_reserve(mid_comm *comm, size_t max_frame_bytes, int k);
 int mid_comm_rank(mid_comm *comm, int *rank, int *world);
 int mid_comm_loopback(mid_comm *comm, const void *src, void *dst, size_t bytes, void *stream);
+int mid_comm_last_loopback(mid_comm *comm, float t_ms[2]);
 int mid_nlm_temporal_sharded(mid_comm *comm, const mid_nlm_params *p, const void *const *block /* count device frames */,
                              int n_frames, int k, mid_pixel *const *out /* count device frames */, void *stream);
 int mid_comm_last_exchange(mid_comm *comm, size_t *bytes_recv, size_t *bytes_sent, float *exchange_ms);

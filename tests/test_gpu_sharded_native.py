@@ -35,10 +35,18 @@ with mid.Comm(ctx, uid, 0, 1) as comm:
     rng = np.random.default_rng(5)
     frame = rng.random((h, w, 4), dtype=np.float32)
     src, dst = ctx.upload(frame), ctx.zeros(frame.nbytes)
+    try:
+        comm.last_loopback()
+        raise SystemExit("a loopback timeline before any loopback")
+    except mid.MidError as e:
+        assert e.code == 1, str(e)
     comm.loopback(src.ptr, dst.ptr, frame.nbytes)
     ctx.sync()
     assert np.array_equal(ctx.download(dst, frame.shape, np.float32), frame)
     rep["loopback_bytes"] = frame.nbytes
+    t0, t1 = comm.last_loopback()
+    assert 0.0 <= t0 < t1 < 1000.0, (t0, t1)
+    rep["loopback_ms"] = [t0, t1]
     # the sharded entry point with one rank
     h, w, n, k = 70, 130, 7, 2
     seq = [(rng.random((h, w, 4), dtype=np.float32) * 0.8).astype(np.float32) for _ in range(n)]
@@ -51,6 +59,12 @@ with mid.Comm(ctx, uid, 0, 1) as comm:
     for i in range(n):
         assert np.array_equal(ctx.download(d_out[i], (h, w, 4), np.float32), whole[i]), i
     rep["last_exchange"] = comm.last_exchange()
+    # a loopback afterwards has its own events: the sharded call's timeline reads the same before and after it
+    tl = comm.last_timeline()
+    comm.loopback(src.ptr, dst.ptr, frame.nbytes)
+    ctx.sync()
+    assert comm.last_timeline() == tl and tl["end_ms"] > 0.0 and 0.0 < tl["interior_end_ms"] <= tl["end_ms"], tl
+    rep["timeline_kept"] = True
     # argument errors surface as codes, not crashes
     try:
         comm.nlm_temporal_sharded_dev([d.ptr for d in d_in[:3]], [d.ptr for d in d_out[:3]], w, h, n, k, 0.5, (-10, 11), (-3, 4), 0)
@@ -103,6 +117,7 @@ def test_one_rank_communicator_loopback_and_sharded_temporal_nlm(tmp_path):
     rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("SHARD1 ")][0][7:])
     assert rep["loopback_bytes"] == 1920 * 1080 * 16
     assert rep["last_exchange"] == [0, 0, 0.0]                     # one rank: nothing to exchange
+    assert rep["timeline_kept"] and rep["loopback_ms"][1] > rep["loopback_ms"][0]
     assert rep["stream_rule"] == "refused, then accepted" and rep["abort"] == "refused afterwards"
 
 

@@ -876,6 +876,7 @@ def main():
                 order = comm.last_issue_order()
                 rc_n, rc_rank, rc_ver = comm.rccl_info()        # what RCCL itself reports for this communicator
                 prio = comm.stream_priority()
+                bprio = comm.boundary_priority()
             hidden = tl["halo_hidden_frac"]
             per_rank = [te, float(recv), float(sent), float(xms), 1.0 if same else 0.0,
                         tl["exchange_start_ms"], tl["exchange_end_ms"], tl["interior_end_ms"], tl["end_ms"],
@@ -889,6 +890,7 @@ def main():
                 rows = [per_rank]
             nat, strong = native_temporal_report(rows, n_seq, world, rehearse, order, prio, rc_ver,
                                                  [c for _, c in sharding.partition(n_seq, world)])
+            nat["boundary_stream_priority"] = list(bprio)       # the device's lowest: a pool of hardware queues of their own (LABNOTES R6.3)
             also["temporal_nlm_k2_native"] = nat
             res["scaling_strong"] = strong
 

@@ -119,6 +119,7 @@ _SIGNATURES = {
     "mid_comm_last_issue_order": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.c_size_t]),
     "mid_comm_rccl_info": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "mid_comm_stream_priority": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "mid_comm_boundary_priority": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
     "mid_image_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Image)]),
     "mid_image_free": (None, [ctypes.POINTER(Image)]),
     "mid_image_load_pinned": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(Image)]),

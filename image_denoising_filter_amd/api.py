@@ -519,6 +519,12 @@ class Comm:
         _check(lib.mid_comm_stream_priority(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "mid_comm_stream_priority")
         return a.value, b.value, c.value
 
+    def boundary_priority(self):
+        """Priorities of the two boundary streams (the device's lowest: a pool of hardware queues of their own)."""
+        pr = (ctypes.c_int * 2)()
+        _check(lib.mid_comm_boundary_priority(self.handle, pr), "mid_comm_boundary_priority")
+        return pr[0], pr[1]
+
     def rccl_info(self):
         """(ncclCommCount, ncclCommUserRank, ncclGetVersion) as RCCL reports them; -1 where the loaded library lacks the call."""
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
         // Read-ahead (MID_BIL_READAHEAD, experiment of round 6): the two tile rows of group g+1 are requested from LDS while
         // group g is still computing, so that a wave never issues a ds_read_b128 and waits for it in the next instruction.
         constexpr int RG = 2;
-        constexpr bool RA = MID_BIL_READAHEAD != 0;
+        constexpr bool RA = MID_BIL_READAHEAD != 0 && MODE == 0 && R <= 8;   // (wider windows and the two-tile modes: the allocation explodes, see LABNOTES R6.4)
         float4 ng[RG], nc[RG];
         if constexpr (RA) {
 #pragma unroll

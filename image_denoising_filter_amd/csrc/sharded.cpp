@@ -8,15 +8,24 @@
 // ONE exchange step -- ncclSend/ncclRecv inside one group, point to point with the neighbouring rank(s); no all-reduce,
 // no all-gather -- after which the rank filters its block with the same kernels as a single GPU does.
 //
-//   stream (caller's)   : [e0] interior outputs ............................ [wait b1] done
-//   exchange stream     : [wait e0] group{recv halo, send edges} [e1]
-//   boundary stream     : [wait e0] [wait e1] boundary outputs ....... [b1]
+//   stream (caller's)   : [e0] interior outputs ............................ [wait b1[0], b1[1]] done
+//   exchange stream     : [wait e0] group{recv halo, send edges} [e1]            (highest priority)
+//   boundary stream 0   : [wait e0] [wait e1] low-edge outputs ..... [b1[0]]     (lowest priority)
+//   boundary stream 1   : [wait e0] [wait e1] high-edge outputs .... [b1[1]]     (lowest priority)
 //
 // Interior outputs (windows inside the rank's own block) are launched while the halo is in flight; the <= 2k boundary
-// outputs wait for it ON THEIR OWN STREAM, so that their workgroups fill the tail of the interior launch instead of
-// queueing behind it: at 8 frames per rank (64 frames on 8 GPUs, k = 2) the three launches are 9.03 + 4.5 + 4.5 rounds of
-// workgroups -- 20.0 ms back to back on one stream, 18.8 ms with the boundary launches on a second one, which is what ONE
-// launch over the 8 outputs takes (tools/boundary_stream_probe.py, LABNOTES R5.5).  The caller's stream joins at the end.  The launch plan (which outputs are interior, which frame table each launch sees) is the one
+// outputs wait for it ON STREAMS OF THEIR OWN, one per edge, so that their workgroups fill the tail of the interior launch
+// instead of queueing behind it: at 8 frames per rank (64 frames on 8 GPUs, k = 2) the three launches are 9.03 + 4.5 + 4.5
+// rounds of workgroups -- 19.9-20.0 ms back to back on one stream, 18.8 ms with each boundary launch on its own
+// lowest-priority stream, which is what ONE launch over the 8 outputs takes (tools/boundary_stream_probe.py,
+// profiles/r06_boundary_stream_priority.txt, LABNOTES R6.3).  Why the LOWEST priority: the runtime gives every priority
+// level its own pool of four hardware queues, and a queue runs its packets in order.  At the default priority a boundary
+// stream lands in the pool the caller's streams live in -- in a PyTorch process that pool is shared by torch's 32 pooled
+// streams, and a boundary stream that shares the caller's queue gains nothing (19.95 ms; 18.8 only with
+// GPU_MAX_HW_QUEUES=8 in the environment).  The lowest level is the library's alone: two boundary streams, two queues,
+// whatever the application created; and workgroups of that level are dispatched where no interior workgroup waits, which
+// is exactly the tail.  (ONE lowest-priority stream for both edges: 19.2 ms -- the second edge launch starts when the first
+// has drained and pays a tail of its own.)  The caller's stream joins both at the end.  The launch plan (which outputs are interior, which frame table each launch sees) is the one
 // image_denoising_filter_amd/sharding.py::block_launch_plan states and the gloo tests pin; mid_shard_* expose it as pure
 // host functions so that the C++ and Python statements are tested against each other on the CPU.
 //
@@ -199,9 +208,10 @@ struct mid_comm {
     hipEvent_t e0 = nullptr, e1 = nullptr, x0 = nullptr;
     hipEvent_t l0 = nullptr, l1 = nullptr, lq = nullptr;   // mid_comm_loopback's own events: queued (caller's stream), start and end (exchange stream)
     bool have_loop = false;
-    hipStream_t bs = nullptr;               // boundary stream: the launches that wait for the halo run here, beside the interior launches' tail
-    hipEvent_t b1 = nullptr;                // end of the boundary launches on bs; the caller's stream waits for it before `done`
-    bool bs_used = false;                   // this call queued something on bs (the join is then owed, also on an error path)
+    hipStream_t bs[2] = {nullptr, nullptr}; // boundary streams (lowest priority), one per edge of the block: the launches that wait for the halo run here, in the interior launches' tail
+    hipEvent_t b1[2] = {nullptr, nullptr};  // end of the boundary launch on bs[j]; the caller's stream waits for them before `done`
+    bool bs_used[2] = {false, false};       // this call queued something on bs[j] (the join is then owed, also on an error path)
+    int bs_priority = 0;
     hipEvent_t i1 = nullptr;                // end of the interior launches on the caller's stream (timeline only)
     hipEvent_t done = nullptr;              // end of the last sharded call's launches, on the stream it was issued on
     bool have_i1 = false, have_done = false;
@@ -236,8 +246,11 @@ static int comm_finish_create(mid_comm *c)
     MID_HIP(hipEventCreate(&c->lq));
     MID_HIP(hipEventCreate(&c->i1));
     MID_HIP(hipEventCreate(&c->done));
-    MID_HIP(hipStreamCreateWithFlags(&c->bs, hipStreamNonBlocking));
-    MID_HIP(hipEventCreateWithFlags(&c->b1, hipEventDisableTiming));
+    c->bs_priority = least;
+    for (int j = 0; j < 2; ++j) {
+        MID_HIP(hipStreamCreateWithPriority(&c->bs[j], hipStreamNonBlocking, least));
+        MID_HIP(hipEventCreateWithFlags(&c->b1[j], hipEventDisableTiming));
+    }
     return MID_OK;
 }
 
@@ -359,8 +372,10 @@ extern "C" int mid_comm_destroy(mid_comm *c)
     if (c->x0) (void)hipEventDestroy(c->x0);
     for (hipEvent_t e : {c->l0, c->l1, c->lq}) if (e) (void)hipEventDestroy(e);
     if (c->i1) (void)hipEventDestroy(c->i1);
-    if (c->b1) (void)hipEventDestroy(c->b1);
-    if (c->bs) { (void)hipStreamSynchronize(c->bs); (void)hipStreamDestroy(c->bs); }
+    for (int j = 0; j < 2; ++j) {
+        if (c->b1[j]) (void)hipEventDestroy(c->b1[j]);
+        if (c->bs[j]) { (void)hipStreamSynchronize(c->bs[j]); (void)hipStreamDestroy(c->bs[j]); }
+    }
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->xs) (void)hipStreamDestroy(c->xs);
     delete c;
@@ -480,10 +495,11 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
         ~Finish()
         {
             if (!armed) return;
-            if (c->bs_used) {                                      // the caller's stream continues only after the boundary stream's work
-                if (hipEventRecord(c->b1, c->bs) != hipSuccess || hipStreamWaitEvent(s, c->b1, 0) != hipSuccess)
-                    (void)hipStreamSynchronize(c->bs);             // (a broken device: fall back to a host-side join)
-                c->bs_used = false;
+            for (int j = 0; j < 2; ++j) {
+                if (!c->bs_used[j]) continue;                      // the caller's stream continues only after the boundary streams' work
+                if (hipEventRecord(c->b1[j], c->bs[j]) != hipSuccess || hipStreamWaitEvent(s, c->b1[j], 0) != hipSuccess)
+                    (void)hipStreamSynchronize(c->bs[j]);          // (a broken device: fall back to a host-side join)
+                c->bs_used[j] = false;
             }
             // `done` is what the next call's stream rule and reserve_halo's "may the retired buffers go" test: it must stand
             // behind THIS call's work.  If it cannot be recorded (a broken device), a stale `done` of an older call would answer
@@ -519,31 +535,35 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
         for (size_t i = 0; i < rv.size(); ++i) if (rv[i].frame == f) return c->halo[i];
         return nullptr;
     };
-    for (int phase = 1; phase >= 0; --phase) {                    // interior launches first, then (after the halo) the boundary ones
-        hipStream_t ls = b.s;
-        if (phase == 0) {
-            // every interior launch is on the caller's stream by now; the boundary launches go to the boundary stream, which is
-            // ordered behind the block's frames (e0) and -- only here -- told to wait for the exchange
-            MID_HIP(hipEventRecord(c->i1, b.s));
-            c->have_i1 = true;
-            bool any = false;
-            for (const Launch &L : plan) any = any || !L.interior;
-            if (!any) break;
-            ls = c->bs;
-            c->bs_used = true;
-            MID_HIP(hipStreamWaitEvent(c->bs, c->e0, 0));
-            if (c->timed) { MID_HIP(hipStreamWaitEvent(c->bs, c->e1, 0)); c->issued += 'W'; }
+    auto launch = [&](const Launch &L, hipStream_t ls) -> int {
+        std::vector<const void *> tbl(L.w_hi - L.w_lo + 1);
+        for (int f = L.w_lo; f <= L.w_hi; ++f) {
+            tbl[f - L.w_lo] = frame_ptr(f);
+            MID_REQUIRE(tbl[f - L.w_lo], "nlm_temporal_sharded: frame %d is neither in the block nor in the halo (plan error)", f);
         }
-        for (const Launch &L : plan) {
-            if (L.interior != phase) continue;
-            std::vector<const void *> tbl(L.w_hi - L.w_lo + 1);
-            for (int f = L.w_lo; f <= L.w_hi; ++f) {
-                tbl[f - L.w_lo] = frame_ptr(f);
-                MID_REQUIRE(tbl[f - L.w_lo], "nlm_temporal_sharded: frame %d is neither in the block nor in the halo (plan error)", f);
-            }
-            if (int rc = mid_nlm_temporal(c->ctx, p, tbl.data(), (int)tbl.size(), k, L.first, L.count, out + L.off, ls)) return rc;
-            c->issued += phase ? 'I' : 'B';
+        return mid_nlm_temporal(c->ctx, p, tbl.data(), (int)tbl.size(), k, L.first, L.count, out + L.off, ls);
+    };
+    // interior launches first, on the caller's stream ...
+    for (const Launch &L : plan) {
+        if (!L.interior) continue;
+        if (int rc = launch(L, b.s)) return rc;
+        c->issued += 'I';
+    }
+    MID_HIP(hipEventRecord(c->i1, b.s));
+    c->have_i1 = true;
+    // ... then the boundary launches, each edge of the block on its own lowest-priority stream: ordered behind the block's
+    // frames (e0) and -- only here, after every interior launch has been queued -- told to wait for the exchange
+    int edge = 0;
+    for (const Launch &L : plan) {
+        if (L.interior) continue;
+        const int j = edge++ & 1;
+        if (!c->bs_used[j]) {
+            c->bs_used[j] = true;
+            MID_HIP(hipStreamWaitEvent(c->bs[j], c->e0, 0));
+            if (c->timed) { MID_HIP(hipStreamWaitEvent(c->bs[j], c->e1, 0)); c->issued += 'W'; }
         }
+        if (int rc = launch(L, c->bs[j])) return rc;
+        c->issued += 'B';
     }
     return MID_OK;                                                 // (`finish` records `done`)
 }
@@ -587,12 +607,22 @@ extern "C" int mid_comm_last_timeline(mid_comm *c, float t_ms[4])
 }
 
 // What the last sharded call put on its streams, in host issue order: 'X' the exchange group (exchange stream), 'I' an
-// interior launch (caller's stream), 'W' the boundary stream's wait for the exchange, 'B' a boundary launch (boundary stream).  The overlap of halo and interior
-// compute is structural when every 'I' precedes the 'W' (tests/test_gpu_sharded_multirank.py asserts it).
+// interior launch (caller's stream), 'W' a boundary stream's wait for the exchange, 'B' a boundary launch (on that boundary
+// stream): "X I.. W B [W B]".  The overlap of halo and interior compute is structural when every 'I' precedes the first 'W'
+// (tests/test_gpu_sharded_multirank.py asserts it).
 extern "C" int mid_comm_last_issue_order(mid_comm *c, char *buf, size_t buflen)
 {
     MID_REQUIRE(c && buf && buflen > 0, "comm_last_issue_order: bad argument");
     snprintf(buf, buflen, "%s", c->issued.c_str());
+    return MID_OK;
+}
+
+extern "C" int mid_comm_boundary_priority(mid_comm *c, int priority[2])
+{
+    MID_REQUIRE(c && priority, "comm_boundary_priority: NULL argument");
+    Bind b(c->ctx, nullptr);
+    if (b.rc) return b.rc;
+    for (int j = 0; j < 2; ++j) MID_HIP(hipStreamGetPriority(c->bs[j], &priority[j]));
     return MID_OK;
 }
 

@@ -287,11 +287,16 @@ int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const void *host_t
  *   t[0] exchange start, t[1] exchange end (both 0 when nothing was exchanged), t[2] end of the interior launches, t[3] end of
  *   the last launch.  The share of the exchange hidden behind interior compute is (min(t[1], t[2]) - t[0]) / (t[1] - t[0]).
  * mid_comm_last_issue_order: what the call put on its streams, in host issue order -- 'X' exchange group (exchange stream), 'I'
- *   interior launch (caller's stream), 'W' the wait for the exchange, 'B' boundary launch (both on the communicator's boundary
- *   stream, so that boundary workgroups fill the interior launch's tail; the caller's stream joins it before the call's work is
- *   complete on that stream); every 'I' precedes the 'W' by construction.
+ *   interior launch (caller's stream), then per edge of the block 'W' the wait for the exchange and 'B' the boundary launch, on
+ *   that edge's boundary stream of the communicator ("X I.. W B W B"), so that boundary workgroups fill the interior launch's
+ *   tail; the caller's stream joins both before the call's work is complete on it; every 'I' precedes the first 'W' by construction.
  * mid_comm_stream_priority: the exchange stream's priority and the device's range (numerically lower = higher); the stream
- *   is created with the highest, so RCCL's send/receive kernels are dispatched ahead of queued interior workgroups. */
+ *   is created with the highest, so RCCL's send/receive kernels are dispatched ahead of queued interior workgroups.
+ * mid_comm_boundary_priority: the two boundary streams' priority -- the device's LOWEST (`least`).  Streams and hardware queues:
+ *   the HIP runtime gives each of its three priority levels a pool of four hardware queues and a queue runs its packets in order,
+ *   so two busy streams that share a queue serialise.  The library's streams are placed so that this cannot happen among them,
+ *   whatever the application creates: highest level = upload, download, exchange (3 of 4 queues); lowest level = the two boundary
+ *   streams (2 of 4); default level = the context's two kernel streams, beside the caller's own streams. */
 typedef struct mid_comm mid_comm;
 #define MID_COMM_ID_BYTES 128
 int mid_shard_block(int n_frames, int world, int rank, int *start, int *count);
@@ -313,6 +318,7 @@ int mid_comm_last_exchange(mid_comm *comm, size_t *bytes_recv, size_t *bytes_sen
 int mid_comm_last_timeline(mid_comm *comm, float t_ms[4]);
 int mid_comm_last_issue_order(mid_comm *comm, char *buf, size_t buflen);
 int mid_comm_stream_priority(mid_comm *comm, int *priority, int *least, int *greatest);
+int mid_comm_boundary_priority(mid_comm *comm, int priority[2]);
 /* What RCCL itself reports for the communicator: ncclCommCount, ncclCommUserRank, ncclGetVersion (-1 where unavailable). */
 int mid_comm_rccl_info(mid_comm *comm, int *nranks, int *user_rank, int *version);
 

@@ -106,7 +106,7 @@ def test_the_sharded_paths_report_is_assembled_for_worlds_this_pool_cannot_run()
             edge = r in (0, world - 1)
             recv = (2 if edge else 4) * bench.NPIX * 16
             rows.append([0.020 + 0.001 * r, float(recv), float(recv), 0.45, 1.0, 0.02, 0.47, 9.0 + r, 19.0, 1.0 if r else 0.8, float(world), float(r)])
-        nat, strong = bench.native_temporal_report(rows, 64, world, False, "XIWBB", (-1, 1, -1), 22606, frames)
+        nat, strong = bench.native_temporal_report(rows, 64, world, False, "XIWBWB", (-1, 1, -1), 22606, frames)
         json.dumps({"a": nat, "b": strong})
         assert strong["n_gpus"] == world and strong["scaling"] == "strong" and strong["frames_per_rank"] == frames
         assert strong["value"] == round(64 * bench.NPIX / 1e6 / (0.020 + 0.001 * (world - 1)), 1)            # max over ranks sets the time

@@ -21,9 +21,12 @@ def hip_runtime():
 hip = hip_runtime()
 lo, hi = ctypes.c_int(), ctypes.c_int()
 assert hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo), ctypes.byref(hi)) == 0
-raw = ctypes.c_void_p()
-assert hip.hipStreamCreateWithPriority(ctypes.byref(raw), 1, lo.value) == 0                     # 1 = hipStreamNonBlocking
-sLow = torch.cuda.ExternalStream(raw.value)
+def raw_stream(prio):
+    raw = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithPriority(ctypes.byref(raw), 1, prio) == 0                     # 1 = hipStreamNonBlocking
+    return torch.cuda.ExternalStream(raw.value)
+sLow, sLow2 = raw_stream(lo.value), raw_stream(lo.value)
+sB2 = torch.cuda.Stream()
 print("stream priority range: least %d, greatest %d; boundary stream variants: default (0) and least" % (lo.value, hi.value), flush=True)
 W, H, S, P = bench.W, bench.H, (-10, 11), (-3, 4)
 def interior(s): ctx.nlm_temporal_dev(fp[2:10], op[2:6], W, H, 0.5, S, P, 2, 2, 4, 0, s)       # outputs 4..7 of the 12: windows of 5
@@ -36,6 +39,12 @@ def two_streams(sB=sB):
     interior(sA.cuda_stream); edge_lo(sB.cuda_stream); edge_hi(sB.cuda_stream)
     e2 = torch.cuda.Event(); e2.record(sB); sA.wait_event(e2)
 def two_streams_low(): two_streams(sLow)
+def three_streams(s1=sB, s2=sB2):                      # each boundary launch on a stream of its own
+    e = torch.cuda.Event(); e.record(sA); s1.wait_event(e); s2.wait_event(e)
+    interior(sA.cuda_stream); edge_lo(s1.cuda_stream); edge_hi(s2.cuda_stream)
+    for s_ in (s1, s2):
+        e2 = torch.cuda.Event(); e2.record(s_); sA.wait_event(e2)
+def three_streams_low(): three_streams(sLow, sLow2)
 def clock(fn, n=20):
     fn(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,10 +53,13 @@ def clock(fn, n=20):
     b.record(sA); torch.cuda.synchronize()
     return a.elapsed_time(b) / n
 for rep in range(3):
-    print("one stream %.3f ms | boundary launches on a second stream %.3f ms | on a second stream of the LOWEST priority %.3f ms | one launch of 8 outputs %.3f ms" % (
-        clock(one_stream), clock(two_streams), clock(two_streams_low), clock(lambda: ctx.nlm_temporal_dev(fp, op, W, H, 0.5, S, P, 2, 2, 8, 0, sA.cuda_stream))), flush=True)
+    print("one stream %.3f ms | boundary launches on a second stream %.3f ms | on a second stream of the LOWEST priority %.3f ms | "
+          "each boundary launch on its own stream %.3f ms | ... both of the LOWEST priority %.3f ms | one launch of 8 outputs %.3f ms" % (
+        clock(one_stream), clock(two_streams), clock(two_streams_low), clock(three_streams), clock(three_streams_low), clock(lambda: ctx.nlm_temporal_dev(fp, op, W, H, 0.5, S, P, 2, 2, 8, 0, sA.cuda_stream))), flush=True)
 ref = [o.clone() for o in outs]; two_streams(); torch.cuda.synchronize()
 one_stream(); torch.cuda.synchronize()
 print("outputs equal between the arrangements:", all(torch.equal(a, b) for a, b in zip(ref, outs)))
-two_streams_low(); torch.cuda.synchronize()
-print("... and with the lowest-priority boundary stream:", all(torch.equal(a, b) for a, b in zip(ref, outs)))
+for fn in (two_streams_low, three_streams, three_streams_low):
+    for o in outs: o.zero_()
+    fn(); torch.cuda.synchronize()
+    print("... and", fn.__name__, all(torch.equal(a, b) for a, b in zip(ref, outs)))

@@ -43,7 +43,9 @@ CASES = (("0", 16, 270, 480, 0), ("30", 16, 270, 480, 0), ("10", 16, 1080, 1920,
          ("0", 4, 1080, 1920, 8), ("0", 16, 1080, 1920, 8), ("0", 4, 1080, 1920, 32), ("0", 16, 1080, 1920, 32))
 for lib in (sys.argv[1:] or [""]):
     for delay, n, h, w, wgs in CASES:
-        env = dict(os.environ, MID_RCCL_LIBRARY=standin, STANDIN_RCCL_DELAY_MS=delay, GPU_MAX_HW_QUEUES="24")
+        env = dict(os.environ, MID_RCCL_LIBRARY=standin, STANDIN_RCCL_DELAY_MS=delay)
+        if os.environ.get("PROBE_HW_QUEUES"):       # round 5 ran this probe with 24 hardware queues per level; since round 6 the runtime's default (4) is the case of interest
+            env["GPU_MAX_HW_QUEUES"] = os.environ["PROBE_HW_QUEUES"]
         if wgs:
             env["STANDIN_RCCL_COPY_WGS"] = str(wgs)
         if lib:

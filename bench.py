@@ -990,7 +990,8 @@ def main():
                 # exactly SEQ_FRAMES frames whatever --frames is: the first XF resident frames cycled (the keys say _64)
                 hf = [f.cpu().numpy() for f in frames[:XF]]
                 lf8 = [np.clip(f * 64.0, 0, 255).astype(np.uint8) for f in hf]
-                also["pipeline_pcie_inclusive_ldr_64"] = pipeline_passes([lf8[i % len(lf8)] for i in range(SEQ_FRAMES)], out_u8=True)
+                # (six passes: a pass that follows a host-side gap runs 8 % slower on the device's clocks, profiles/r06_pipe_u8_spread.txt)
+                also["pipeline_pcie_inclusive_ldr_64"] = pipeline_passes([lf8[i % len(lf8)] for i in range(SEQ_FRAMES)], out_u8=True, passes=6)
                 r = pipeline_passes([hf[i % len(hf)] for i in range(SEQ_FRAMES)], out_u8=False)
                 c = also.get("pipeline_pcie_inclusive", {}).get("pcie_ceiling")
                 if c:

@@ -18,10 +18,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef MID_BIL_READAHEAD
-#define MID_BIL_READAHEAD 0
-#endif
-
 namespace mid {
 
 struct BilArgs {
@@ -146,20 +142,6 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
 #pragma unroll
         for (int k = 0; k < P; ++k) { acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); accw[k] = 0.f; }
 
-        // Read-ahead (MID_BIL_READAHEAD, experiment of round 6): the two tile rows of group g+1 are requested from LDS while
-        // group g is still computing, so that a wave never issues a ds_read_b128 and waits for it in the next instruction.
-        constexpr int RG = 2;
-        constexpr bool RA = MID_BIL_READAHEAD != 0 && MODE == 0 && R <= 8;   // (wider windows and the two-tile modes: the allocation explodes, see LABNOTES R6.4)
-        float4 ng[RG], nc[RG];
-        if constexpr (RA) {
-#pragma unroll
-            for (int r = 0; r < RG; ++r) {
-                if (r >= MR) continue;
-                const int t = (wv * P + r) * LW + lane;               // column offset i = -R
-                ng[r] = gde_t[t];
-                if (MODE != 0) nc[r] = img_t[t];
-            }
-        }
         for (int i = -R; i <= R; ++i) {
             const float si = a.ks * (float)(i * i);
             float sij[R + 1];
@@ -172,42 +154,20 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
             // cycles (tools/microbench10/11.hip: 8 exps + 88 FMAs 357 cycles per group per SIMD against 67 + 211 alone; 274
             // with s_setprio around the exp burst); scheduling barriers keep the three phases apart.
             // Same instructions per tap, same accumulation order: identical output bits.
+            // (Each group's two ds_read_b128 are followed directly by their first use.  Issuing them one group ahead was measured in
+            // round 6 and buys nothing -- 8 waves per SIMD cover the LDS latency already; profiles/r06_ab_bilateral_readahead.txt.)
+            constexpr int RG = 2;
 #pragma unroll
             for (int m0 = 0; m0 < MR; m0 += RG) {
                 float4 cc[RG];
-                float4 gg[RG];
                 float ar[RG][P];
-                if constexpr (RA) {
-#pragma unroll
-                    for (int r = 0; r < RG; ++r) { gg[r] = ng[r]; cc[r] = MODE != 0 ? nc[r] : ng[r]; }
-                    if (m0 + RG < MR) {
-#pragma unroll
-                        for (int r = 0; r < RG; ++r) {
-                            const int m = m0 + RG + r;
-                            if (m >= MR) continue;
-                            ng[r] = gde_t[base + m * LW];
-                            if (MODE != 0) nc[r] = img_t[base + m * LW];
-                        }
-                    } else if (i < R) {                                // the first group of the next column offset
-#pragma unroll
-                        for (int r = 0; r < RG; ++r) {
-                            if (r >= MR) continue;
-                            ng[r] = gde_t[base + 1 + r * LW];
-                            if (MODE != 0) nc[r] = img_t[base + 1 + r * LW];
-                        }
-                    }
-                }
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
                     const int m = m0 + r;
                     if (m >= MR) continue;
-                    float4 g;
-                    if constexpr (RA) g = gg[r];
-                    else {
-                        g = gde_t[base + m * LW];
-                        cc[r] = g;
-                        if (MODE != 0) cc[r] = img_t[base + m * LW];
-                    }
+                    const float4 g = gde_t[base + m * LW];
+                    cc[r] = g;
+                    if (MODE != 0) cc[r] = img_t[base + m * LW];
 #pragma unroll
                     for (int k = 0; k < P; ++k) {
                         const int j = m - R - k;

@@ -136,7 +136,13 @@ int mid_host_unregister(mid_ctx *ctx, void *hptr);
  * 8 MiB chunks through page-locked bounce buffers the context owns (32 MiB, allocated on first use), and the call returns
  * when src_host has been consumed (h2d; the last chunks may still be in flight on `stream`) or dst_host holds the data (d2h).
  * The same holds for every host frame handed to mid_sequence_nlm* / mid_nlm_multiframe.  Pageable copies cost a host memcpy
- * on top of the DMA (measured: see LABNOTES R5.1), so decode into pinned memory when throughput matters. */
+ * on top of the DMA (measured: see LABNOTES R5.1), so decode into pinned memory when throughput matters.
+ * Threads: a context has ONE pair of bounce buffers per direction, guarded by a lock the copying thread holds from its first chunk
+ * to its last, INCLUDING the waits for `stream` to reach each chunk.  Pageable copies of one direction on one context are therefore
+ * serialised, also across independent streams, and two threads must not make them depend on each other: if thread A's copy sits on a
+ * stream that waits (hipStreamWaitEvent) for work queued behind thread B's pageable copy of the same direction on the same context,
+ * A holds the lock while its stream waits for B and B waits for the lock -- a deadlock.  Pinned copies take no lock; threads that
+ * need independent pageable copies use one context each (contexts share nothing). */
 int mid_memcpy_h2d(mid_ctx *ctx, void *dst, const void *src_host, size_t bytes, void *stream);  /* LoadImageDataToBuffer + copy-to-texture, src/main.cpp:1105-1142,990-1076 */
 int mid_memcpy_d2h(mid_ctx *ctx, void *dst_host, const void *src, size_t bytes, void *stream);  /* vkCmdCopyBuffer to staging + GetImageFromGPU, src/main.cpp:835-840,91-123 */
 int mid_memset(mid_ctx *ctx, void *dst, int value, size_t bytes, void *stream);                 /* the reference never clears its weight buffer; callers of *_accum must */

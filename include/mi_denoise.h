@@ -155,8 +155,9 @@ int mid_stream_sync(mid_ctx *ctx, void *stream);                     /* vkWaitFo
 int mid_bilateral(mid_ctx *ctx, const mid_bilateral_params *p,
                   const void *in, mid_pixel *out, void *stream);
 /* The same dispatch for n_frames independent frames of one size in ONE launch (grid = tiles x frames): what the
- * reference does by calling RunOnGPU once per file (src/main.cpp:1952-1985), without the per-launch tail -- a 1080p
- * frame is 2.66 rounds of workgroups, a batch fills every round.  in/out: host arrays of n_frames device pointers.
+ * reference does by calling RunOnGPU once per file (src/main.cpp:1952-1985) in one launch instead of n (measured: the same
+ * rate per frame -- at r = 8 a 1080p frame is 2040 workgroups on 1024 slots, four 40 KB tiles per CU, 1.99 rounds, so there is
+ * little tail to save; tools/microbench19.hip).  in/out: host arrays of n_frames device pointers.
  * Results are bit-identical to n_frames calls of mid_bilateral (same tile code).
  * No aliasing: an `out` buffer must not be any `in` buffer of the same call (all frames are filtered concurrently) nor
  * appear twice; mid_bilateral likewise rejects in == out.  Violations return MID_ERR_INVALID. */

@@ -125,6 +125,7 @@ _SIGNATURES = {
     "mid_image_load_pinned": (ctypes.c_int, [_P, ctypes.c_char_p, ctypes.POINTER(Image)]),
     "mid_image_free_pinned": (ctypes.c_int, [_P, ctypes.POINTER(Image)]),
     "mid_image_save": (ctypes.c_int, [ctypes.c_char_p, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "mid_image_threads": (ctypes.c_int, [ctypes.c_int]),
     "mid_timer_create": (ctypes.c_int, [_P, c_void_pp]),
     "mid_timer_destroy": (ctypes.c_int, [_P]),
     "mid_timer_tick": (ctypes.c_int, [_P, _P]),

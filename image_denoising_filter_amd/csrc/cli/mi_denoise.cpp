@@ -28,6 +28,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -63,6 +64,7 @@ struct Options {
     bool halo_rccl = false;         // animation mode: blocks resident in HBM, halo frames GPU to GPU over RCCL (mid_nlm_temporal_sharded)
     bool pageable_host = false;     // reference modes: keep decoded images and results in ordinary memory (the C-ABI bounces them)
     long pinned_mb = 16384;         // animation mode: at most this much page-locked host memory (inputs + outputs); the rest is pageable
+    int io_threads = 0;             // animation mode: files decoded / encoded at a time (0 = min(16, hardware threads))
 };
 
 #define MID_CHECK(call)                                                                          \
@@ -131,11 +133,18 @@ class DenoiseApplication {
         HostImage(const HostImage &) = delete;
         HostImage &operator=(const HostImage &) = delete;
         HostImage(HostImage &&o) noexcept : w(o.w), h(o.h), format(o.format), pin_ctx(o.pin_ctx), img(o.img) { o.img.data = nullptr; }
-        ~HostImage()
+        HostImage &operator=(HostImage &&o) noexcept
+        {
+            if (this != &o) { release(); w = o.w; h = o.h; format = o.format; pin_ctx = o.pin_ctx; img = o.img; o.img.data = nullptr; }
+            return *this;
+        }
+        void release()
         {
             if (!img.data) return;
             if (pin_ctx) (void)mid_image_free_pinned(pin_ctx, &img); else mid_image_free(&img);
+            img.data = nullptr;
         }
+        ~HostImage() { release(); }
         size_t size() const { return (size_t)w * h * (format == MID_FMT_RGBA32F ? 16 : 4); }
         const uint8_t *data() const { return (const uint8_t *)img.data; }
     };
@@ -153,6 +162,30 @@ class DenoiseApplication {
     }
 
     std::string out_path(const std::string &name) const { return (fs::path(opt.outdir) / name).string(); }
+
+    // Files of a sequence are decoded / encoded CONCURRENTLY, one file per worker thread: the reference does its image I/O on one
+    // thread (lodepng / tinyexr calls, src/main.cpp:155,196,1699,1717), and a PNG's inflate is one serial stream, so files taken
+    // one after the other leave all but one core idle for most of the time.  fn(i) runs for i in [first, n) on `files_at_a_time()`
+    // threads; each of them lets its codec calls use the host threads that are left (mid_image_threads: all of them with
+    // --io-threads 1, one with a file per host thread).  The first exception ends the loop and is rethrown here.
+    int host_threads() const { return (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())); }
+    int files_at_a_time(int n) const { return std::max(1, std::min(opt.io_threads > 0 ? opt.io_threads : host_threads(), n)); }
+    template <class Fn> void for_each_file(int first, int n, Fn fn) const
+    {
+        if (n <= first) return;
+        const int nt = files_at_a_time(n - first), codec_threads = std::max(1, host_threads() / nt);
+        std::atomic<int> next{first};
+        std::vector<std::string> err(nt);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                (void)mid_image_threads(codec_threads);
+                try { for (int i = next++; i < n; i = next++) fn(i); }
+                catch (const std::exception &e) { err[t] = e.what(); next = n; }
+            });
+        for (auto &t : th) t.join();
+        for (auto &e : err) if (!e.empty()) throw std::runtime_error(e);
+    }
 
 public:
     explicit DenoiseApplication(const Options &o) : opt(o) {}
@@ -255,8 +288,11 @@ public:
                 list.insert(list.end(), frameNames.begin(), frameNames.end());
                 if (execAndCopyOverlap && list.size() > 9) list.resize(9);
             }
-            std::vector<HostImage> frames;
-            for (auto &f : list) { frames.push_back(load(f, false, pin)); check_dims(frames.back(), f); }
+            std::vector<HostImage> frames(list.size());
+            for_each_file(0, (int)list.size(), [&](int i) {
+                frames[i] = load(list[i], false, pin);
+                check_dims(frames[i], list[i]);
+            });
             std::vector<const void *> ptrs;
             for (auto &f : frames) ptrs.push_back(f.data());
             mid_nlm_params p{w, h, opt.nlm_h, opt.search_lo, opt.search_hi, opt.patch_lo, opt.patch_hi, fmt};
@@ -277,15 +313,20 @@ public:
                 timed(m_execMs, [&] { MID_CHECK(mid_nlm_temporal(ctx, &p, fr, 1, 0, 0, 1, ou, nullptr)); });
             } else if (useLayers) {                                                             // :1608-1623 + normalize
                 std::vector<void *> dLayers;
-                for (auto &ln : layerNames) {
+                std::vector<HostImage> layerImgs(layerNames.size());
+                for_each_file(0, (int)layerNames.size(), [&](int i) {
+                    layerImgs[i] = load(layerNames[i], true, pin);
+                });
+                for (size_t li = 0; li < layerNames.size(); ++li) {
+                    const std::string &ln = layerNames[li];
                     std::cout << "\t\tfeeding layer to texture\n";
-                    HostImage l = load(ln, true, pin);
+                    HostImage &l = layerImgs[li];
                     if (l.w != w || l.h != h) throw std::runtime_error(ln + ": layer size differs from the target image");
                     void *d = nullptr;
                     MID_CHECK(mid_alloc(ctx, l.size(), &d));
                     dLayers.push_back(d);
                     timed(m_transferMs, [&] { MID_CHECK(mid_memcpy_h2d(ctx, d, l.data(), l.size(), nullptr)); });
-                    MID_CHECK(mid_stream_sync(ctx, nullptr));             // `l` is released at the end of this iteration
+                    MID_CHECK(mid_stream_sync(ctx, nullptr));             // (the decoded layers are released with `layerImgs`)
                 }
                 mid_bilateral_params p{w, h, opt.sigma_s, opt.sigma_c, opt.radius, MID_LAYOUT_TEXTURE, fmt};
                 timed(m_execMs, [&] {
@@ -362,19 +403,28 @@ public:
         size_t pinned_bytes = 0, frame_bytes_guess = 0;
         int n_pageable = 0;
         const auto tl0 = std::chrono::steady_clock::now();
-        for (auto &f : frameNames) {
+        // Frame 0 is decoded first (its size fixes how many frames fit the page-locked budget: inputs and outputs share it frame
+        // by frame, input i is pinned only if output i can be as well); the others are decoded concurrently (for_each_file).
+        pin.frames.assign(n, mid_image{});
+        pin.frame_pinned.assign(n, 0);
+        auto decode = [&](int i, bool pinned) {            // throws on a bad file; falls back to pageable memory when no pinned memory is left
             mid_image img{};
-            // inputs and outputs share the budget frame by frame: input i is pinned only if output i can be as well
-            bool pinned = pinned_budget > 0 && pinned_bytes + 2 * frame_bytes_guess <= pinned_budget;   // (the first frame's size is not known yet: any non-zero budget admits it)
-            if (pinned && mid_image_load_pinned(io, f.c_str(), &img)) pinned = false;      // no page-locked memory left (or a bad file: the pageable load below reports that)
-            if (!pinned && mid_image_load(f.c_str(), &img)) throw std::runtime_error(mid_last_error());
-            pin.frames.push_back(img);
-            pin.frame_pinned.push_back(pinned ? 1 : 0);
-            if (img.width != pin.frames[0].width || img.height != pin.frames[0].height || img.format != pin.frames[0].format)
-                throw std::runtime_error(f + ": size/format differs from the first frame");
-            frame_bytes_guess = (size_t)img.width * img.height * (img.format == MID_FMT_RGBA32F ? 16 : 4);
-            if (pinned) pinned_bytes += 2 * frame_bytes_guess; else ++n_pageable;
-        }
+            if (pinned && mid_image_load_pinned(io, frameNames[i].c_str(), &img)) pinned = false;
+            if (!pinned && mid_image_load(frameNames[i].c_str(), &img)) throw std::runtime_error(mid_last_error());
+            pin.frames[i] = img;
+            pin.frame_pinned[i] = pinned ? 1 : 0;
+        };
+        decode(0, pinned_budget > 0);                       // (the first frame's size is not known yet: any non-zero budget admits it)
+        frame_bytes_guess = (size_t)pin.frames[0].width * pin.frames[0].height * (pin.frames[0].format == MID_FMT_RGBA32F ? 16 : 4);
+        const size_t n_pin = pinned_budget / (2 * frame_bytes_guess);     // frames whose input AND output fit the budget
+        const int io_threads = files_at_a_time(n);
+        for_each_file(1, n, [&](int i) {
+            decode(i, (size_t)i < n_pin);
+            const mid_image &a = pin.frames[i], &b = pin.frames[0];
+            if (a.width != b.width || a.height != b.height || a.format != b.format)
+                throw std::runtime_error(frameNames[i] + ": size/format differs from the first frame");
+        });
+        for (int i = 0; i < n; ++i) { if (pin.frame_pinned[i]) pinned_bytes += 2 * frame_bytes_guess; else ++n_pageable; }
         const double load_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
         const int w = pin.frames[0].width, h = pin.frames[0].height, fmt = pin.frames[0].format;
         // LDR frames come back as RGBA8: the read-back conversion of GetImageFromGPU (:97-103) runs on the device
@@ -525,15 +575,18 @@ public:
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         m_execMs = *std::max_element(kern.begin(), kern.end());
         m_transferMs = *std::max_element(copy.begin(), copy.end());
-        std::cout << "\tdecoded " << n << " frames into pinned memory in " << load_sec << " sec; device set-up + warm-up " << warm_sec << " sec\n";
+        std::cout << "\tdecoded " << n << " frames into pinned memory in " << load_sec << " sec (" << io_threads << " file(s) at a time); device set-up + warm-up " << warm_sec << " sec\n";
         std::cout << "\t" << n << " frames, k=" << k << ", " << G << " device(s): " << sec << " sec, "
                   << (double)n * w * h / 1e6 / sec << " Mpixel/s end to end (host frames in -> host frames out)\n";
-        for (int i = 0; i < n; ++i) {
+        // SaveEXR :1699 / lodepng::encode :1717, straight from the pinned results -- one file per worker thread, like the decode
+        const auto te0 = std::chrono::steady_clock::now();
+        for_each_file(0, n, [&](int i) {
             const std::string name = "output-animation-" + fs::path(frameNames[i]).stem().string() + (hdr ? ".exr" : ".png");
-            if (!hdr) std::cout << "\t\tencoding png\n";
-            // SaveEXR :1699 / lodepng::encode :1717, straight from the pinned result
-            MID_CHECK(mid_image_save(out_path(name).c_str(), pin.outs[i], w, h, hdr ? MID_FMT_RGBA32F : MID_FMT_RGBA8));
-        }
+            if (mid_image_save(out_path(name).c_str(), pin.outs[i], w, h, hdr ? MID_FMT_RGBA32F : MID_FMT_RGBA8)) throw std::runtime_error(mid_last_error());
+        });
+        if (!hdr) for (int i = 0; i < n; ++i) std::cout << "\t\tencoding png\n";
+        std::cout << "\tencoded " << n << " frames in " << std::chrono::duration<double>(std::chrono::steady_clock::now() - te0).count()
+                  << " sec (" << io_threads << " file(s) at a time)\n";
     }
 
     void save(std::string name, const Pixel *px, int w, int h, bool hdr) const
@@ -605,6 +658,7 @@ static void usage()
         "                            then moves every copy through its own pinned bounce buffers -- same files, slower copies\n"
         "  --pinned-mb M             animation mode: page-lock at most M MiB of host memory for frames in and out (default 16384);\n"
         "                            frames beyond that, or whose page-locked allocation fails, use pageable memory\n"
+        "  --io-threads T            animation mode: decode / encode T files at a time, one per host thread (default min(16, hardware threads))\n"
         "  --cpu-radius R --cpu-sigma-s S --cpu-sigma-c C   CPU path (default 10 10.0 0.2)\n"
         "  --cpu-threads A,B         thread counts of the CPU runs (default 1,8)\n"
         "  --cpu-fix-blue            use the blue channel in the CPU range distance (the reference does not)\n";
@@ -636,6 +690,7 @@ int main(int argc, char **argv)
         else if (a == "--gpus") opt.gpus = atoi(next());
         else if (a == "--share-device") opt.share_device = true;
         else if (a == "--pinned-mb") opt.pinned_mb = atol(next());
+        else if (a == "--io-threads") opt.io_threads = atoi(next());
         else if (a == "--pageable-host") opt.pageable_host = true;
         else if (a == "--halo") { const std::string v = next(); if (v == "rccl") opt.halo_rccl = true; else if (v != "host") { usage(); return EXIT_FAILURE; } }
         else if (a == "--cpu-radius") opt.cpu_radius = atoi(next());

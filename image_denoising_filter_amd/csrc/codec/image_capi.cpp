@@ -72,6 +72,14 @@ extern "C" int mid_image_free_pinned(mid_ctx *ctx, mid_image *img)
     return MID_OK;
 }
 
+extern "C" int mid_image_threads(int n)
+{
+    int &cap = codec::thread_cap();
+    const int before = cap;
+    if (n >= 0) cap = n > 256 ? 256 : n;
+    return before;
+}
+
 extern "C" void mid_image_free(mid_image *img)
 {
     if (img && img->data) { free(img->data); img->data = nullptr; }

@@ -13,11 +13,21 @@
 namespace mid {
 namespace codec {
 
-// Blocks of an image file are independent: run fn(i) for i in [0,n) on up to 16 host threads.
+// How many host threads an image call made by THIS thread may use (mid_image_threads): 0 = the default, the machine's
+// hardware concurrency capped at 16.  Per calling thread, so that a host which decodes or encodes many files at once -- one
+// per thread, the way mi_denoise --animation does -- sets 1 on its workers without touching anyone else's calls.
+inline int &thread_cap()
+{
+    static thread_local int cap = 0;
+    return cap;
+}
+
+// Blocks of an image file are independent: run fn(i) for i in [0,n) on up to thread_cap() (default 16) host threads.
 inline void parallel_for(size_t n, const std::function<void(size_t)> &fn)
 {
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 4, 16), n);
+    const size_t cap = thread_cap() > 0 ? (size_t)thread_cap() : std::min<size_t>(hw ? hw : 4, 16);
+    const size_t nt = std::min<size_t>(cap, n);
     if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
     std::atomic<size_t> next{0};
     std::vector<std::thread> th;

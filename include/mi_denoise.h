@@ -348,6 +348,14 @@ void mid_image_free(mid_image *img);
 int  mid_image_load_pinned(mid_ctx *ctx, const char *path, mid_image *out);
 int  mid_image_free_pinned(mid_ctx *ctx, mid_image *img);
 int  mid_image_save(const char *path, const void *data, int32_t width, int32_t height, int32_t format);
+/* The codecs work on the independent blocks of a file in parallel (EXR chunks; PNG: filter rows and 1 MiB deflate segments on
+ * encode -- the inflate of a PNG is one serial stream): by default on up to min(16, hardware threads) host threads per call.
+ * mid_image_threads(n) sets that number FOR IMAGE CALLS MADE BY THE CALLING THREAD (n = 0: the default again, n < 0: query only)
+ * and returns the previous setting.  A host that loads or saves many files at once -- one per thread -- sets 1 on those threads:
+ * mi_denoise --animation decodes and encodes its frames that way (64 x 1080p PNG: the serial inflate of one file no longer
+ * serialises the sequence).  File bytes do not depend on the thread count.  The reference does its image I/O on one thread
+ * (lodepng / tinyexr calls, src/main.cpp:155,196,1699,1717). */
+int  mid_image_threads(int n);
 
 /* ---- measurement helper -----------------------------------------------------------------
  * Timestamps around a region on a stream (reference: vkCmdWriteTimestamp pool,

@@ -176,6 +176,16 @@ def test_animation_mode_ldr_frames_come_back_as_u8(tmp_path):
     out.mkdir()
     r = _run([str(d / "Animation01_X_0000.png"), "--animation", "--temporal-k", "1", "--outdir", str(out)], tmp_path)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "decoded 5 frames" in r.stdout and "file(s) at a time" in r.stdout and "encoded 5 frames" in r.stdout
+    assert r.stdout.count("encoding png") == 5
+    # one file at a time (--io-threads 1) writes the same bytes as one file per worker thread
+    out1 = tmp_path / "o1"
+    out1.mkdir()
+    r1 = _run([str(d / "Animation01_X_0000.png"), "--animation", "--temporal-k", "1", "--outdir", str(out1), "--io-threads", "1"], tmp_path)
+    assert r1.returncode == 0 and "(1 file(s) at a time)" in r1.stdout, r1.stdout + r1.stderr
+    for i in range(5):
+        name = f"output-animation-Animation01_X_{i:04d}.png"
+        assert (out1 / name).read_bytes() == (out / name).read_bytes(), i
     ref = oracle.nlm_temporal([oracle.unpack_u8(f, 0) for f in frames], k=1)
     for i in range(5):
         got = mid.load_image(out / f"output-animation-Animation01_X_{i:04d}.png")

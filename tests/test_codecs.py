@@ -517,3 +517,35 @@ def test_exr_piz_mixed_channel_types_and_corruption(tmp_path):
             assert e.code == 5
             bad += 1
     assert bad > 0
+
+
+def test_image_threads_is_per_calling_thread_and_does_not_change_the_bytes(tmp_path):
+    """mid_image_threads(n): how many host threads an image call of the CALLING thread may use (0 = default, < 0 = query).
+    The setting is thread-local, and the files (PNG: 1 MiB deflate segments; EXR: 16-line ZIP chunks) and decoded pixels are the
+    same bytes whatever it is -- what mi_denoise --animation relies on when it decodes / encodes one file per worker thread."""
+    import threading
+    rng = np.random.default_rng(3)
+    u8 = rng.integers(0, 256, (300, 1200, 4), dtype=np.uint8)          # 1.44 MB raw: two deflate segments
+    f32 = (rng.random((70, 90, 4), dtype=np.float32) * 4).astype(np.float32)
+    assert mid.lib.mid_image_threads(-1) == 0                           # the default
+    files = {}
+    for cap in (0, 1, 3):
+        assert mid.lib.mid_image_threads(cap) in (0, 1, 3)
+        assert mid.lib.mid_image_threads(-1) == cap
+        for name, arr in (("a.png", u8), ("a.exr", f32)):
+            path = tmp_path / f"{cap}_{name}"
+            mid.save_image(path, arr)
+            assert np.array_equal(mid.load_image(path), arr)
+            files.setdefault(name, []).append(path.read_bytes())
+    assert all(b == files["a.png"][0] for b in files["a.png"]) and all(b == files["a.exr"][0] for b in files["a.exr"])
+    seen = {}
+
+    def other():
+        seen["before"] = mid.lib.mid_image_threads(-1)                  # this thread never set anything: the default
+        mid.lib.mid_image_threads(7)
+        seen["after"] = mid.lib.mid_image_threads(-1)
+    t = threading.Thread(target=other)
+    t.start(); t.join()
+    assert seen == {"before": 0, "after": 7} and mid.lib.mid_image_threads(-1) == 3
+    assert mid.lib.mid_image_threads(0) == 3 and mid.lib.mid_image_threads(-1) == 0
+

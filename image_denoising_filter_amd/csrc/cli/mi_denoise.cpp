@@ -598,7 +598,9 @@ public:
             name += ".png";
             std::cout << "\t\tencoding png\n";
             std::vector<unsigned char> resultData((size_t)w * h * 4);
-            for (size_t i = 0; i < (size_t)w * h; ++i) {                                              // GetImageFromGPU :97-103
+            const long npx = (long)w * h;
+#pragma omp parallel for default(shared) schedule(static)
+            for (long i = 0; i < npx; ++i) {                                                          // GetImageFromGPU :97-103
                 const float v[4] = {255.0f * px[i].r, 255.0f * px[i].g, 255.0f * px[i].b, 255.0f * px[i].a};
                 for (int c = 0; c < 4; ++c)      // truncation; clamped only where the C cast is undefined
                     resultData[i * 4 + c] = !(v[c] > -1.0f) ? 0 : v[c] >= 256.0f ? 255 : (unsigned char)v[c];

@@ -211,7 +211,6 @@ struct mid_comm {
     hipStream_t bs[2] = {nullptr, nullptr}; // boundary streams (lowest priority), one per edge of the block: the launches that wait for the halo run here, in the interior launches' tail
     hipEvent_t b1[2] = {nullptr, nullptr};  // end of the boundary launch on bs[j]; the caller's stream waits for them before `done`
     bool bs_used[2] = {false, false};       // this call queued something on bs[j] (the join is then owed, also on an error path)
-    int bs_priority = 0;
     hipEvent_t i1 = nullptr;                // end of the interior launches on the caller's stream (timeline only)
     hipEvent_t done = nullptr;              // end of the last sharded call's launches, on the stream it was issued on
     bool have_i1 = false, have_done = false;
@@ -246,7 +245,6 @@ static int comm_finish_create(mid_comm *c)
     MID_HIP(hipEventCreate(&c->lq));
     MID_HIP(hipEventCreate(&c->i1));
     MID_HIP(hipEventCreate(&c->done));
-    c->bs_priority = least;
     for (int j = 0; j < 2; ++j) {
         MID_HIP(hipStreamCreateWithPriority(&c->bs[j], hipStreamNonBlocking, least));
         MID_HIP(hipEventCreateWithFlags(&c->b1[j], hipEventDisableTiming));

@@ -1020,6 +1020,32 @@ def main():
 
         guarded("pipeline_k2", extra_pipeline_k2)
 
+        def extra_image_io():
+            if rank == 0 and world == 1:
+                # what the drop-in COMMAND spends per file around the GPU work -- the library's own PNG / EXR codecs
+                # (mid_image_save / mid_image_load, host only; the reference calls lodepng / tinyexr, src/main.cpp:155,196,1699,1717)
+                # on one 1080p frame of the bench's data, a call's internal parallelism at its default (up to 16 host threads).
+                import tempfile
+                f32 = frames[0].cpu().numpy()
+                u8 = np.clip(f32 * 64.0, 0, 255).astype(np.uint8)
+                out = {}
+                with tempfile.TemporaryDirectory() as d:
+                    for name, arr in (("png", u8), ("exr", f32)):
+                        path = os.path.join(d, "f." + name)
+                        enc, dec = [], []
+                        for _ in range(3):
+                            t0 = time.perf_counter(); mid.save_image(path, arr); enc.append(time.perf_counter() - t0)
+                            t0 = time.perf_counter(); back = mid.load_image(path); dec.append(time.perf_counter() - t0)
+                        assert np.array_equal(back, arr)
+                        out[name] = {"encode_ms": round(sorted(enc)[1] * 1e3, 1), "decode_ms": round(sorted(dec)[1] * 1e3, 1),
+                                     "file_MB": round(os.path.getsize(path) / 1e6, 2)}
+                out["note"] = ("one 1920x1080 frame per call, median of 3, host threads as the library picks them (min(16, hardware threads)); a PNG's inflate "
+                               "is one serial stream, which is why mi_denoise takes the files of a sequence one per worker thread "
+                               "(profiles/r06_cli_animation_time.txt: 64 files 7.2 -> 2.45 s end to end, of which the GPU 0.04 s)")
+                also["image_io_1080p"] = out
+
+        guarded("image_io", extra_image_io)
+
     res["also"] = also
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

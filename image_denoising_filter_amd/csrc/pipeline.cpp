@@ -114,7 +114,9 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
     const int n_up = f_hi - f_lo + 1;
     // Outputs could be filtered in batches of B frames per launch.  Measured on MI355X (16 x 1080p, 21x21/7x7):
     // B=1 2084 Mpixel/s, B=2 1341, B=4 1472, B=8 1403 -- coarser batches bunch the copies and lose overlap
-    // while the kernel time barely changes, so one frame per launch it is (the indexing below stays general in B).
+    // while the kernel time barely changes, so one frame per launch it is (the indexing below stays general in B).  Re-measured in
+    // round 6 for RGBA8 frames with direct output stores (no download stage to bunch): B = 1 / 2 / 4 4096-4109 / 4106-4121 / 4107-4132
+    // Mpixel/s, k = 2 898-904 / 907 / 906 -- the same (profiles/r06_pipe_batch_u8_ab.txt).
     constexpr int B = 1;
     const int nb = (count + B - 1) / B;
     constexpr int DEPTH = 4;                                  // batches in flight per stage

@@ -29,6 +29,7 @@
 #include <stdexcept>
 #include <string>
 #include <atomic>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -176,13 +177,16 @@ class DenoiseApplication {
         const int nt = files_at_a_time(n - first), codec_threads = std::max(1, host_threads() / nt);
         std::atomic<int> next{first};
         std::vector<std::string> err(nt);
+        auto worker = [&](int t) {
+            const int before = mid_image_threads(codec_threads);
+            try { for (int i = next++; i < n; i = next++) fn(i); }
+            catch (const std::exception &e) { err[t] = e.what(); next = n; }
+            (void)mid_image_threads(before);
+        };
         std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t)
-            th.emplace_back([&, t] {
-                (void)mid_image_threads(codec_threads);
-                try { for (int i = next++; i < n; i = next++) fn(i); }
-                catch (const std::exception &e) { err[t] = e.what(); next = n; }
-            });
+        try { for (int t = 1; t < nt; ++t) th.emplace_back(worker, t); }
+        catch (const std::system_error &) {}              // no more threads to be had: the ones that started (and this one) do the work
+        worker(0);                                         // the calling thread is worker 0
         for (auto &t : th) t.join();
         for (auto &e : err) if (!e.empty()) throw std::runtime_error(e);
     }

@@ -7,7 +7,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <exception>
 #include <functional>
+#include <mutex>
+#include <system_error>
 #include <thread>
 
 namespace mid {
@@ -30,10 +33,18 @@ inline void parallel_for(size_t n, const std::function<void(size_t)> &fn)
     const size_t nt = std::min<size_t>(cap, n);
     if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
     std::atomic<size_t> next{0};
+    std::exception_ptr failed;                // the first exception a block raised (std::bad_alloc, say): rethrown on the calling thread
+    std::mutex failed_mu;
+    auto worker = [&] {
+        try { for (size_t i = next++; i < n; i = next++) fn(i); }
+        catch (...) { std::lock_guard<std::mutex> l(failed_mu); if (!failed) failed = std::current_exception(); next = n; }
+    };
     std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; ++t)
-        th.emplace_back([&] { for (size_t i = next++; i < n; i = next++) fn(i); });
+    try { for (size_t t = 1; t < nt; ++t) th.emplace_back(worker); }
+    catch (const std::system_error &) {}      // no more threads to be had (EAGAIN under a thread limit): the ones that started, and this one, do the work
+    worker();                                 // the calling thread is one of the workers
     for (auto &t : th) t.join();
+    if (failed) std::rethrow_exception(failed);
 }
 
 // The decoders write straight into memory the caller provides: `alloc(n)` is called exactly once, after the header

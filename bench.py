@@ -703,23 +703,24 @@ def main():
             # the other, 10 launches each, whichever came SECOND read 3-6 % slower (rounds 1-2: 0.181 vs 0.193 ms; the
             # profiler's launch mix, which runs texture first, and an interleaved A/B both show them equal, LABNOTES.md rounds 1-3 section 3.2):
             # 2 ms of 0.18 ms launches between host-side gaps sit on the GPU's clock ramp.  So: warm both, then alternate
-            # them (order flipped every repetition), 20 launches per timing, and report each layout's median.
+            # them (order flipped every repetition), 40 launches per timing (20 until round 6: 3 ms bursts still sat on the ramp and
+            # hid a 3 % kernel gain that the 16-frame batch and a longer A/B showed), and report each layout's median.
             layouts = (("bilateral_r8_linear", mid.LAYOUT_LINEAR), ("bilateral_r8_texture", mid.LAYOUT_TEXTURE))
             fns = {name: (lambda lay=layout: ctx.bilateral_dev(fptr[0], optr[0], W, H, 8, 2.0, 0.2, lay, mid.FMT_RGBA32F, stream))
                    for name, layout in layouts}
             for name, _ in layouts:
-                time_gpu(fns[name], 20)
+                time_gpu(fns[name], 40)
             samples = {name: [] for name, _ in layouts}
             for rep in range(7):
                 for name, _ in (layouts if rep % 2 == 0 else layouts[::-1]):
-                    samples[name].append(time_gpu(fns[name], 20))
+                    samples[name].append(time_gpu(fns[name], 40))
             for name, _ in layouts:
                 s = sorted(samples[name])[len(samples[name]) // 2]
                 also[name] = {"Mpixel/s": round(NPIX / 1e6 / s, 1), "ms": round(s * 1e3, 4), "ms_min": round(min(samples[name]) * 1e3, 4),
                               "valu_frac": round(BIL_FLOP_PER_PX * NPIX / s / 1e12 / PEAK_FP32_TFLOPS, 4),
                               "hbm_GBs": round(BIL_BYTES_PER_PX * NPIX / s / 1e9, 1),
                               "hbm_frac": round(BIL_BYTES_PER_PX * NPIX / s / 1e9 / PEAK_HBM_GBS, 5),
-                              "timing": "median of 7 interleaved timings of 20 launches"}
+                              "timing": "median of 7 interleaved timings of 40 launches"}
             also["bilateral_r8_texture_over_linear"] = round(also["bilateral_r8_texture"]["ms"] / also["bilateral_r8_linear"]["ms"], 4)
 
         guarded("bilateral", extra_bilateral)

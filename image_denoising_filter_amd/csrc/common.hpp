@@ -180,8 +180,9 @@ __device__ __forceinline__ float4 fetch_linear(const void *img, int w, int h, in
 // Consecutive threads take consecutive texels of a tile row: 16 B/lane coalesced HBM reads.
 template <int FMT, bool LINEAR>
 __device__ __forceinline__ void fill_tile(float4 *lds, int tw, int th, const void *img, int w, int h,
-                                          int x0, int y0, int tid, int nthreads, float rgb_scale = 1.0f)
+                                          int x0, int y0, int tid, int nthreads, float rgb_scale = 1.0f, bool *opaque = nullptr)
 {
+    // `opaque` (optional): and-ed with "every texel THIS thread stored has alpha == 1.0f" (out-of-image texels are vec4(0): not opaque)
     // four texels per thread per trip: the four global loads are in flight together, so a tile costs
     // about n/(4*nthreads) memory latencies instead of n/nthreads
     const int n = tw * th;
@@ -201,6 +202,7 @@ __device__ __forceinline__ void fill_tile(float4 *lds, int tw, int th, const voi
             // rgb_scale is 1 except for the NLM strip kernels (exponent scale folded into the colours);
             // x * 1.0f is exact, and alpha is never scaled
             if (t < n) lds[t] = make_float4(v[j].x * rgb_scale, v[j].y * rgb_scale, v[j].z * rgb_scale, v[j].w);
+            if (opaque && t < n) *opaque = *opaque && v[j].w == 1.0f;
         }
     }
 }

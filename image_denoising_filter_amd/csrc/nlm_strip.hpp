@@ -189,12 +189,12 @@ void nlm_strip_kernel(const NlmArgs a)
             Tr[m] = t.x * a.sk; Tg[m] = t.y * a.sk; Tb[m] = t.z * a.sk;
         }
     }
-    auto fill = [&](const void *nb) {
+    auto fill = [&](const void *nb, bool *opaque) {
         if constexpr (FMT == kFmtRuntime) {
-            if (a.fmt == MID_FMT_RGBA8) fill_tile<MID_FMT_RGBA8, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo, tid, NW * 64, a.sk);
-            else fill_tile<MID_FMT_RGBA32F, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo, tid, NW * 64, a.sk);
+            if (a.fmt == MID_FMT_RGBA8) fill_tile<MID_FMT_RGBA8, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo, tid, NW * 64, a.sk, opaque);
+            else fill_tile<MID_FMT_RGBA32F, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo, tid, NW * 64, a.sk, opaque);
         } else {
-            fill_tile<FMT, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo, tid, NW * 64, a.sk);
+            fill_tile<FMT, false>(lds, LW, LH, nb, w, h, X0 + PLO + slo, Y0 + PLO + slo, tid, NW * 64, a.sk, opaque);
         }
     };
 
@@ -206,8 +206,25 @@ void nlm_strip_kernel(const NlmArgs a)
     for (int f = f_lo; f <= f_hi; ++f) {
         const void *nb = FUSED ? a.frames.p[f] : a.neighbour;
         __syncthreads();   // previous frame's readers are done with the tile
-        fill(nb);
-        __syncthreads();
+        // Is every texel of the neighbour tile opaque (alpha == 1.0f -- the usual case away from the image border, where the tile
+        // holds out-of-image texels, vec4(0))?  Then sum(wt * alpha) IS sum(wt) and the weight accumulator need not be carried
+        // through the offsets: normWeight = 0.001 + weightColor.w at the end of the frame -- one add per output and offset less
+        // (8 of 199 VALU) and eight registers free.  Round 6, the tuned windows only (kOpaqueForm): 31-frame launches +1.6 %, the
+        // RGBA8 frame pipeline +2-3.5 %, temporal k = 2 +7-8 %; a lone frame -3.6 %, because the loop now exists twice (30 KB each)
+        // and a single-frame launch runs two kernels side by side (profiles/r06_ab_nlm_opaque_form.txt, LABNOTES R6.8).  The form is
+        // chosen per workgroup and neighbour frame from the tile's CONTENT, and every launch shape of a window -- batched, single,
+        // HALF tail, accumulate-only, temporal -- carries both forms, so a pixel's bits do not depend on the launch.  (In the opaque
+        // form the 0.001 is added after the weights instead of before them: the last bit of normWeight, nothing else.)
+        constexpr bool kOpaqueForm = !RTS;
+        bool opaque = false;
+        if constexpr (kOpaqueForm) {
+            bool mine = true;
+            fill(nb, &mine);
+            opaque = __syncthreads_and(mine) != 0;
+        } else {
+            fill(nb, nullptr);
+            __syncthreads();
+        }
         if (!wave_active) continue;
 
         float4 acc[R];
@@ -239,7 +256,7 @@ void nlm_strip_kernel(const NlmArgs a)
         // one offset of a run: window row r lives in register slot (j + r) % DR
         // (LT: std::bool_constant -- the lower half of a strip in the HALF shape; the two halves are two copies of the loop, chosen
         // per wave by a scalar branch around a whole run, so that each copy is straight-line code)
-        auto step = [&](auto LT, int j, float4 (&n)[DR], const float4 *nextp, bool more) {
+        auto step = [&](auto LT, auto A1, int j, float4 (&n)[DR], const float4 *nextp, bool more) {
             float D[DR];
 #pragma unroll
             for (int m = 0; m < DR; ++m) {
@@ -271,35 +288,44 @@ void nlm_strip_kernel(const NlmArgs a)
                 const float4 c = n[(j + k + NL) % DR];            // centre texel Nb(p+s) of output row k = window row k + NL
                 acc[k].x = fmaf(c.x, wt, acc[k].x); acc[k].y = fmaf(c.y, wt, acc[k].y);   // :56
                 acc[k].z = fmaf(c.z, wt, acc[k].z); acc[k].w = fmaf(c.w, wt, acc[k].w);
-                accw[k] += wt;                                    // :57
+                if constexpr (!decltype(A1)::value) accw[k] += wt;   // :57
             }
             if constexpr (!EARLY) { if (more) n[j % DR] = nextp[0]; }   // (patches that start at row 0: the leaving row was output row 0's centre)
             drop_priority();
         };
         // `steps` <= WALK consecutive search rows at one search column; FULL: steps == WALK is known at compile time
-        auto run = [&](auto LT, const bool FULL, const float4 *colp, int steps) __attribute__((always_inline)) {
+        auto run = [&](auto LT, auto A1, const bool FULL, const float4 *colp, int steps) __attribute__((always_inline)) {
             float4 n[DR];
 #pragma unroll
             for (int m = 0; m < DR; ++m) n[m] = colp[m * LW];
 #pragma unroll
             for (int j = 0; j < WALK; ++j) {
-                if (FULL || j < steps) step(LT, j, n, colp + (DR + j) * LW, FULL ? j + 1 < WALK : j + 1 < steps);
+                if (FULL || j < steps) step(LT, A1, j, n, colp + (DR + j) * LW, FULL ? j + 1 < WALK : j + 1 < steps);
             }
             // rows still in the window that never were centre rows: keep their alpha formally live (see above)
-            const float last_w = accw[R - 1];
+            const float last_w = decltype(A1)::value ? acc[R - 1].w : accw[R - 1];
 #pragma unroll
             for (int m = 0; m < DR; ++m) asm volatile("" ::"v"(n[m].w), "v"(last_w));
         };
-        for (int sy0 = 0; sy0 < SW; sy0 += WALK) {
-            const int steps = sy0 + WALK < SW ? WALK : SW - sy0;
-            const float4 *rowp = lds + (wv * R + sy0) * LW + lane;
-            if (HALF && lower_half) {
-                if (steps == WALK) { for (int sx = 0; sx < SW; ++sx) run(std::bool_constant<HALF>{}, true, rowp + sx, steps); }
-                else { for (int sx = 0; sx < SW; ++sx) run(std::bool_constant<HALF>{}, false, rowp + sx, steps); }
-            } else {
-                if (steps == WALK) { for (int sx = 0; sx < SW; ++sx) run(std::false_type{}, true, rowp + sx, steps); }
-                else { for (int sx = 0; sx < SW; ++sx) run(std::false_type{}, false, rowp + sx, steps); }
+        auto walk = [&](auto A1) {
+            for (int sy0 = 0; sy0 < SW; sy0 += WALK) {
+                const int steps = sy0 + WALK < SW ? WALK : SW - sy0;
+                const float4 *rowp = lds + (wv * R + sy0) * LW + lane;
+                if (HALF && lower_half) {
+                    if (steps == WALK) { for (int sx = 0; sx < SW; ++sx) run(std::bool_constant<HALF>{}, A1, true, rowp + sx, steps); }
+                    else { for (int sx = 0; sx < SW; ++sx) run(std::bool_constant<HALF>{}, A1, false, rowp + sx, steps); }
+                } else {
+                    if (steps == WALK) { for (int sx = 0; sx < SW; ++sx) run(std::false_type{}, A1, true, rowp + sx, steps); }
+                    else { for (int sx = 0; sx < SW; ++sx) run(std::false_type{}, A1, false, rowp + sx, steps); }
+                }
             }
+        };
+        if (kOpaqueForm && opaque) {
+            walk(std::true_type{});
+#pragma unroll
+            for (int k = 0; k < R; ++k) accw[k] = 0.001f + acc[k].w;     // normWeight of this frame: nonlocal.comp:32 + sum(wt)
+        } else {
+            walk(std::false_type{});
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) {   // nlmData[p] += ..., nonlocal.comp:61-62

@@ -106,19 +106,29 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
     if (MODE == 2 && a.n_layers > 0) prefetch(a.layers[0]);      // (no layers: the loop below does not run, the output is the magenta sentinel)
     // The guide colours (the image itself in MODE 0) are pre-multiplied by sqrt(-kc), so -|dc|^2 is already the
     // colour part of the exp2 argument and the FMA chain can start from the spatial term: 12 ops per tap, not 13.
-    fill_tile<FMT, LINEAR>(img_t, LW, LH, in, w, h, X0 - R, Y0 - R, tid, NW * 64, MODE == 0 ? a.sc : 1.0f);
+    bool mine = true;                                     // every texel THIS thread stored in the colour tile has alpha == 1.0f
+    fill_tile<FMT, LINEAR>(img_t, LW, LH, in, w, h, X0 - R, Y0 - R, tid, NW * 64, MODE == 0 ? a.sc : 1.0f, &mine);
 
     // Is every texel of the colour tile opaque (alpha == 1.0f, the usual case away from the image border, where out-of-image
     // texels are vec4(0))?  Then the alpha accumulator repeats the weight accumulator operation for operation --
     // fma(1.0f, wt, acc.w) and accw + wt round alike, both start at 0 -- and the tap loop need not carry it: one FMA of 13
     // instructions per tap less, the same bits.  Round 6: r = 8 0.1541 -> 0.1490 ms (-3.3 %), r = 10 / 20 -3 %, r = 4 -1 %, every
-    // output's sha equal (profiles/r06_ab_bilateral_opaque_alpha.txt, LABNOTES R6.7).
+    // output's sha equal; 4 layers fused at r = 8 0.6443 -> 0.6225 ms (-3.4 %), r = 10 -3.7 %, r = 4 -2 %
+    // (profiles/r06_ab_bilateral_opaque_alpha.txt, LABNOTES R6.7).
+    // How the workgroup agrees.  Plain bilateral: __syncthreads_and (4 B of static LDS: the 40 KB tile then fits three times per
+    // CU instead of four, which this kernel does not notice -- 0.1547-0.1553 against 0.1552-0.1554 ms).  Layer modes: their two
+    // tiles are EXACTLY half the CU's LDS, and one static word would halve the occupancy (+20 %, measured); the guide tile is
+    // still unused at this point, so its first word carries the vote.
     bool alpha_one = false;
-    if constexpr (MODE == 0) {      // (the layer modes lose 20 % with the tap loop in two forms: plain bilateral only)
-        __syncthreads();
-        bool mine = true;
-        for (int t = tid; t < LW * LH; t += NW * 64) mine = mine && img_t[t].w == 1.0f;
+    if constexpr (MODE == 0) {
         alpha_one = __syncthreads_and(mine) != 0;
+    } else {
+        unsigned *vote = (unsigned *)gde_t;
+        if (tid == 0) vote[0] = 1u;
+        __syncthreads();
+        if (!mine) vote[0] = 0u;
+        __syncthreads();
+        alpha_one = __builtin_amdgcn_readfirstlane((int)vote[0]) != 0;      // (the pass loop's first barrier comes before the guide tile is written)
     }
 
     // spatial exponent by |j|: ks * j^2 (wave-uniform)
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(NW * 64) void bilateral_kernel(const BilArgs a, con
             for (int k = 0; k < P; ++k) acc[k].w = accw[k];
         }
         };
-        if (MODE == 0 && alpha_one) taps(std::true_type{}); else taps(std::false_type{});
+        if (alpha_one) taps(std::true_type{}); else taps(std::false_type{});
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             if (MODE == 0) { acc[k].x *= a.inv_sc; acc[k].y *= a.inv_sc; acc[k].z *= a.inv_sc; }   // back to unscaled colours

@@ -27,7 +27,7 @@ def sha(): torch.cuda.synchronize(); return hashlib.sha256(out.cpu().numpy().tob
 for _ in range(3): run(lambda: bil(fr[0], 8, 1))
 res = []
 for name, fn in (("r8 linear", lambda: bil(fr[0], 8, 1)), ("r8 texture", lambda: bil(fr[0], 8, 0)), ("r4", lambda: bil(fr[0], 4, 1)), ("r10", lambda: bil(fr[0], 10, 0)),
-                 ("r20", lambda: bil(fr[0], 20, 0)), ("layers4 r8", lambda: lay4(fr[0], 8)), ("r8 alpha0.5 corner", lambda: bil(fr2, 8, 1)), ("r8 linear", lambda: bil(fr[0], 8, 1))):
+                 ("r20", lambda: bil(fr[0], 20, 0)), ("layers4 r8", lambda: lay4(fr[0], 8)), ("layers4 r4", lambda: lay4(fr[0], 4)), ("layers4 r10", lambda: lay4(fr[0], 10)), ("layers4 r8 alpha0.5 corner", lambda: lay4(fr2, 8)), ("r8 alpha0.5 corner", lambda: bil(fr2, 8, 1)), ("r8 linear", lambda: bil(fr[0], 8, 1))):
     t = sorted(run(fn) for _ in range(7)); fn()
     res.append("%s %.4f (min %.4f) %s" % (name, t[3], t[0], sha()))
 print("AB " + " | ".join(res), flush=True)

@@ -553,3 +553,51 @@ def test_bilateral_batch_chunks_beyond_the_frame_table(ctx):
     got = ctx.bilateral_batch(frames, 4, 2.0, 0.2, "texture")
     for i in (0, 1, 95, 96, 97, 100):
         assert np.array_equal(got[i], ctx.bilateral(frames[i], 4, 2.0, 0.2, "texture")), i
+
+
+# ---- opaque-tile forms (round 6) -------------------------------------------------------------------
+def test_opaque_and_general_tile_forms_agree(ctx):
+    """Where every texel of a tile has alpha == 1.0f the kernels run a shorter loop (csrc/bilateral.hip: no alpha FMA;
+    csrc/nlm_strip.hpp: no weight add, tuned windows).  One texel with alpha = 0.25 in the middle of the frame puts the tiles
+    that see it on the general loop and leaves the others on the short one; alpha enters no weight, so
+      * bilateral (plain and layer-guided): the rgb output of the two frames is the same BITS everywhere -- the forms are
+        bit-identical -- and alpha differs only inside the texel's window;
+      * NLM (bench and reference windows, single frame and temporal): rgb agrees to the last bit or two (the opaque form adds
+        the 0.001 of nonlocal.comp:32 after the weights instead of before them);
+      * both frames match the oracle, alpha included."""
+    rng = np.random.default_rng(77)
+    h, w = 150, 300                                   # 3 x 10 bilateral tiles of 64 x 16, 6 x 5 NLM tiles of 58 x 32: interior tiles exist
+    a = (synth_hdr(rng, h, w) * 0.25).astype(np.float32)
+    a[..., 3] = 1.0                                   # (the scale above applies to alpha too)
+    b = a.copy()
+    b[75, 150, 3] = 0.25
+    for R in (4, 8):
+        for layout in ("texture", "linear"):
+            ga, gb = ctx.bilateral(a, R, 2.0, 0.2, layout), ctx.bilateral(b, R, 2.0, 0.2, layout)
+            assert np.array_equal(ga[..., :3], gb[..., :3]), (R, layout)
+            diff = np.argwhere(ga[..., 3] != gb[..., 3])
+            assert len(diff) and np.all(np.abs(diff - [75, 150]) <= R), (R, layout)
+            ref = oracle.bilateral_texture(b, R, 2.0, 0.2) if layout == "texture" else oracle.bilateral_linear(b, R, 2.0, 0.2)
+            assert rel_err(gb, ref) < BIL_TOL and np.all(ga[R:-R, R:-R, 3] == 1.0)
+    layers = [rng.integers(0, 256, (h, w, 4), dtype=np.uint8) for _ in range(3)]
+    la, lb = ctx.bilateral_layers(a, layers, 8, 2.0, 0.2), ctx.bilateral_layers(b, layers, 8, 2.0, 0.2)
+    assert np.array_equal(la[..., :3], lb[..., :3]) and not np.array_equal(la[..., 3], lb[..., 3])
+    Wl = Z(h, w)
+    for lay in layers:
+        Wl = oracle.bilateral_layers_accum(b, lay, Wl, 8, 2.0, 0.2)
+    assert rel_err(lb, oracle.normalize(Wl)) < BIL_TOL
+    for cfg in ("bench", "ref"):
+        na, nb_ = ctx.nlm_temporal([a], k=0, **NLM_CFGS[cfg])[0], ctx.nlm_temporal([b], k=0, **NLM_CFGS[cfg])[0]
+        assert rel_err(na[..., :3], nb_[..., :3]) < 5e-7, cfg                       # last-bit agreement of the two forms
+        assert rel_err(nb_, oracle.nlm_temporal([b], k=0, **NLM_CFGS[cfg])[0]) < NLM_TOL
+        assert rel_err(na, oracle.nlm_temporal([a], k=0, **NLM_CFGS[cfg])[0]) < NLM_TOL
+        # temporal: the form is chosen per neighbour frame (frame 1 of the window is the one with the odd texel)
+        seq_a, seq_b = [a, np.roll(a, 2, axis=1), a], [a, np.roll(b, 2, axis=1), a]
+        ta, tb = ctx.nlm_temporal(seq_a, k=1, **NLM_CFGS[cfg]), ctx.nlm_temporal(seq_b, k=1, **NLM_CFGS[cfg])
+        rb = oracle.nlm_temporal(seq_b, k=1, **NLM_CFGS[cfg])
+        for t in range(3):
+            assert rel_err(ta[t][..., :3], tb[t][..., :3]) < 5e-7 and rel_err(tb[t], rb[t]) < NLM_TOL, (cfg, t)
+            W = Z(h, w)                                                             # fused == dispatch sequence, bit for bit, on mixed tiles too
+            for f in range(max(0, t - 1), min(2, t + 1) + 1):
+                W = ctx.nlm_accum(seq_b[t], seq_b[f], W, 0.5, **NLM_CFGS[cfg])
+            assert np.array_equal(tb[t], ctx.normalize(W)), (cfg, t)

@@ -204,3 +204,26 @@ def test_sequence_range_blocks_equal_whole(ctx):
     for start, count in ((0, 3), (3, 3), (6, 3), (0, 1), (4, 5), (8, 1)):
         part, _ = ctx.sequence_nlm(frames, k=2, first=start, count=count)
         assert all(np.array_equal(part[i], whole[start + i]) for i in range(count)), (start, count)
+
+
+@pytest.mark.gpu
+def test_animation_with_a_corrupt_frame_fails_cleanly(tmp_path):
+    """One file per worker thread (round 6): a frame that does not decode ends the whole load with the codec's message and exit
+    code 1 -- no crash, no hang of the other workers, nothing written."""
+    d, frames, _, ext = _make_animation(tmp_path, False, n=6)
+    bad = d / f"Animation01_X_0003.{ext}"
+    blob = bytearray(bad.read_bytes())
+    blob[len(blob) // 2] ^= 0xFF                       # inside the IDAT stream: CRC mismatch
+    bad.write_bytes(bytes(blob))
+    out = tmp_path / "o"
+    out.mkdir()
+    r = _run([str(d / f"Animation01_X_0000.{ext}"), "--animation", "--temporal-k", "1", "--outdir", str(out)], tmp_path)
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert "Animation01_X_0003" in r.stdout + r.stderr or "png:" in r.stdout + r.stderr
+    assert not list(out.iterdir())
+    # a frame of another size: named, exit code 1
+    odd = np.zeros((10, 12, 4), np.uint8)
+    mid.save_image(bad, odd)
+    r = _run([str(d / f"Animation01_X_0000.{ext}"), "--animation", "--temporal-k", "1", "--outdir", str(out)], tmp_path)
+    assert r.returncode == 1 and "size/format differs" in r.stdout + r.stderr, r.stdout + r.stderr
+

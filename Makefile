@@ -3,7 +3,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := image_denoising_filter_amd/csrc
 LIB     := image_denoising_filter_amd/libmi_denoise.so
-SRCS    := $(CSRC)/capi.cpp $(CSRC)/hostcopy.cpp $(CSRC)/markers.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/nlm_rt.hip $(CSRC)/nlm_rt4.hip $(CSRC)/pipeline.cpp $(CSRC)/sharded.cpp \
+SRCS    := $(CSRC)/capi.cpp $(CSRC)/hostcopy.cpp $(CSRC)/markers.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/nlm_small.hip $(CSRC)/nlm_rt.hip $(CSRC)/nlm_rt4.hip $(CSRC)/pipeline.cpp $(CSRC)/sharded.cpp \
            $(CSRC)/codec/png.cpp $(CSRC)/codec/exr.cpp $(CSRC)/codec/piz.cpp $(CSRC)/codec/image_capi.cpp
 OBJS    := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 HIPFLAGS := -x hip --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Iinclude
@@ -23,6 +23,8 @@ $(LIB): $(OBJS)
 # Mpixel/s batched, 2882 vs 2710 single frame); the bilateral kernels lose 8 % with it, so it stays off there.
 EXTRA_nlm.hip := -mllvm -amdgpu-sched-strategy=max-ilp
 EXTRA_nlm_rt.hip := $(EXTRA_nlm.hip)
+# small launches of the tuned windows (a lone frame, two, three) are fastest under the iterative-ILP strategy instead: nlm_small.hip
+EXTRA_nlm_small.hip := -mllvm -amdgpu-sched-strategy=iterative-ilp
 EXTRA_nlm_rt4.hip := $(EXTRA_nlm.hip)
 
 build/%.o: $(CSRC)/% $(CSRC)/common.hpp $(CSRC)/nlm_strip.hpp $(CSRC)/codec/image_io.hpp include/mi_denoise.h

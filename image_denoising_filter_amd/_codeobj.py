@@ -21,7 +21,7 @@ _MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 # nlm_strip_kernel<SLO=-10, SHI=11, PLO=-3, PHI=4, R=8, NW=4, FMT=0 (RGBA32F), FUSED, !MULTI, !HALF>: bench.py's timed launch
 # bilateral_kernel<R=8, P=2, NW=8, FMT=0 (RGBA32F), LINEAR, MODE=0, BilOne>: `bench.py --workload bilateral`'s launch
 BENCH_KERNELS = {
-    "nlm": "_ZN3mid16nlm_strip_kernelILin10ELi11ELin3ELi4ELi8ELi4ELi0ELb1ELb0ELb0EEEvNS_7NlmArgsE",
+    "nlm": "_ZN3mid16nlm_strip_kernelILin10ELi11ELin3ELi4ELi8ELi4ELi0ELb1ELb0ELb0ELi0EEEvNS_7NlmArgsE",
     "bilateral": "_ZN3mid16bilateral_kernelILi8ELi2ELi8ELi0ELb1ELi0ENS_6BilOneEEEvNS_7BilArgsET5_",
 }
 

@@ -86,21 +86,6 @@ __global__ __launch_bounds__(256) void nlm_generic_kernel(const NlmArgs a, int s
     }
 }
 
-// The last round of a SMALL launch.  A tuned launch is tiles x frames workgroups of 4 waves, two per CU (76 KB tiles): `slots` at a
-// time.  When the last round fills at most half of the CUs' slots -- one workgroup per CU or fewer -- every wave of it sits alone
-// on its SIMD and issues at half rate, so the round takes as long as a full one: one 1080p frame is 1156 workgroups = 2.26 rounds and
-// pays for 3.  Those workgroups are launched in the HALF shape instead (eight waves on the same tile, half a strip each, same bits:
-// nlm_strip.hpp), which brings two waves per SIMD back and ends the round in 0.6 of the time.  Only for launches of a few rounds:
-// in a long launch the last round is noise, and the headline launch stays ONE kernel.  false = launch everything the usual way.
-static bool tail_split(const mid_ctx *ctx, const NlmArgs &a, int patch_w, bool fused, unsigned &full, unsigned &rem)
-{
-    const unsigned slots = 2u * (unsigned)ctx->cu_count;
-    const unsigned nwg = nlm_tile_workgroups(a.w, a.h, patch_w, fused ? a.count : 1);
-    rem = nwg % slots;
-    full = nwg - rem;
-    return !a.corunning && rem > 0 && rem <= (unsigned)ctx->cu_count && full / slots <= 8;
-}
-
 template <int FMT, bool FUSED>
 static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s)
 {
@@ -108,23 +93,20 @@ static int dispatch_ranges(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hi
     // CU and one computes while the other refills its tile.
     // The strip height is the same for every launch size on purpose: the block-sum decomposition of vertical_box makes the
     // rounding of a pixel depend on its row within the strip, so a fixed R keeps the output bits independent of batch size,
-    // sharding and fused-vs-dispatch-sequence (tested).  The HALF shape of tail_split above splits strips into rows 0-3 / 4-7
+    // sharding and fused-vs-dispatch-sequence (tested).  The HALF shape (nlm_small.hip: tail_split) splits strips into rows 0-3 / 4-7
     // with the 8-row strip's own additions, so it may be used wherever it is faster.
     const bool multi = FUSED && a.k > 0;
+    if (!multi) {   // small launches of the tuned windows (a lone frame, two, three): their own copies of the kernels + the HALF tail, nlm_small.hip
+        bool handled = false;
+        const int rc = nlm_dispatch_small(ctx, p, a, s, FMT, FUSED, &handled);
+        if (handled) return rc;
+    }
     if (p->search_lo == -10 && p->search_hi == 11 && p->patch_lo == -3 && p->patch_hi == 4) {   // 21x21 / 7x7 (benchmark)
         if (multi) return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, FUSED>(ctx, a, s);
-        if (unsigned full, rem; tail_split(ctx, a, 7, FUSED, full, rem)) {
-            if (int rc = launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false>(ctx, a, s, 0, full)) return rc;
-            return launch_strip<-10, 11, -3, 4, 4, 8, FMT, FUSED, false, true>(ctx, a, s, full, rem);
-        }
         return launch_strip<-10, 11, -3, 4, 8, 4, FMT, FUSED, false>(ctx, a, s);
     }
     if (p->search_lo == -7 && p->search_hi == 7 && p->patch_lo == -3 && p->patch_hi == 3) {     // nonlocal.comp:5-6 as shipped
         if (multi) return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, FUSED>(ctx, a, s);
-        if (unsigned full, rem; tail_split(ctx, a, 6, FUSED, full, rem)) {
-            if (int rc = launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false>(ctx, a, s, 0, full)) return rc;
-            return launch_strip<-7, 7, -3, 3, 4, 8, FMT, FUSED, false, true>(ctx, a, s, full, rem);
-        }
         return launch_strip<-7, 7, -3, 3, 8, 4, FMT, FUSED, false>(ctx, a, s);
     }
     // Any other search window: the same strip kernel with the search range -- and the texel format -- as run-time arguments

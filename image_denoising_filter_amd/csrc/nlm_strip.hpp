@@ -123,7 +123,9 @@ constexpr int nlm_min_waves(bool rts, bool multi, int pw)
 // each taking half of an 8-row strip (R = 4; even waves the upper, odd waves the lower four rows) with the strip's own vertical sums
 // (vertical_box_half): identical output bits, 0.6 of a strip's instructions per wave, and two waves per SIMD on a CU that holds this
 // workgroup alone -- where a 4-wave workgroup alone leaves every wave a SIMD to itself at half issue rate.
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, bool HALF = false>
+// TAG: no effect on the code -- it only names a second copy of an instantiation, so that the copies in nlm_small.hip (compiled with another
+// scheduling strategy, see there) and in nlm.hip are different symbols.
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, bool HALF = false, int TAG = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(nlm_min_waves(SLO == 0 && SHI == 0, MULTI, PHI - PLO), 2)))
 void nlm_strip_kernel(const NlmArgs a)
 {
@@ -369,7 +371,7 @@ void nlm_strip_kernel(const NlmArgs a)
     }
 }
 
-template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, bool HALF = false>
+template <int SLO, int SHI, int PLO, int PHI, int R, int NW, int FMT, bool FUSED, bool MULTI, bool HALF = false, int TAG = 0>
 static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s, unsigned wg_first = 0, unsigned wg_count = ~0u)
 {
     constexpr bool RTS = (SLO == 0 && SHI == 0);
@@ -378,7 +380,7 @@ static int launch_strip(mid_ctx *ctx, NlmArgs &a, hipStream_t s, unsigned wg_fir
     const int SW = RTS ? a.shi - a.slo : SHI - SLO;
     const int LW = 64 + SW - 1, LH = TILE_H + PW - 1 + SW - 1;
     const size_t lds_bytes = (size_t)LW * LH * sizeof(float4);
-    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, HALF>;
+    auto kern = nlm_strip_kernel<SLO, SHI, PLO, PHI, R, NW, FMT, FUSED, MULTI, HALF, TAG>;
     if ((int)lds_bytes > ctx->lds_max)
         return set_error(MID_ERR_UNSUPPORTED, "nlm tile needs %zu B of LDS, device offers %d", lds_bytes, ctx->lds_max);
     // run-time-range instantiations are launched with different tile sizes: raise their limit to the device maximum once
@@ -407,5 +409,9 @@ inline unsigned nlm_tile_workgroups(int w, int h, int patch_w, int frames)
 // does not fit the LDS) -- the caller falls back to the per-pixel kernel.
 int nlm_dispatch_rt8(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s, bool fused, bool *handled);
 int nlm_dispatch_rt4(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s, bool fused, bool *handled);
+// Small launches of the tuned windows (at most kNlmSmallRounds rounds of workgroups, not co-running): defined in nlm_small.hip, which holds its
+// own copies of the tuned kernels (TAG = 1) and the HALF shape for the last round.  *handled = false: not a tuned window / not a small launch.
+constexpr unsigned kNlmSmallRounds = 7;
+int nlm_dispatch_small(mid_ctx *ctx, const mid_nlm_params *p, NlmArgs &a, hipStream_t s, int fmt, bool fused, bool *handled);
 
 }  // namespace mid

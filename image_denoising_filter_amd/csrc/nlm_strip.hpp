@@ -212,12 +212,11 @@ void nlm_strip_kernel(const NlmArgs a)
         // holds out-of-image texels, vec4(0))?  Then sum(wt * alpha) IS sum(wt) and the weight accumulator need not be carried
         // through the offsets: normWeight = 0.001 + weightColor.w at the end of the frame -- one add per output and offset less
         // (8 of 199 VALU) and eight registers free.  Round 6, the tuned windows only (kOpaqueForm): 31-frame launches +1.7 %, the
-        // RGBA8 frame pipeline +2-3.5 %, temporal k = 2 +7-8 %; a lone frame -3.6 % -- its main launch is exactly two rounds of
-        // workgroups (490 -> 496 us in the trace; the HALF tail launch is unchanged), all of them in the fill phase at once, so what
-        // the agreement on `opaque` costs there shows, while a long launch hides it behind the co-resident workgroup's arithmetic.
-        // A cheaper agreement (flag words behind the tile, no reduction) was measured: better for the lone frame (-1 %), worse for
-        // everything else (+0.9 % / +4 %) -- the compiler's schedule of this 30 KB loop moves by more than the detection costs
-        // (profiles/r06_ab_nlm_opaque_form.txt, LABNOTES R6.8).  The form is
+        // RGBA8 frame pipeline +2-3.5 %, temporal k = 2 +7-8 %.  A lone frame first LOST 3.6 % -- its main launch is exactly two rounds
+        // of workgroups, all of them in the fill phase at once, where the agreement on `opaque` (a workgroup reduction) shows -- and
+        // got it back from the compiler: launches of a few rounds run copies of these kernels scheduled by LLVM's iterative-ILP
+        // strategy (nlm_small.hip), long ones the max-ILP copies (profiles/r06_ab_nlm_opaque_form.txt, r06_ab_nlm_scheduling.txt,
+        // LABNOTES R6.8-R6.9).  The form is
         // chosen per workgroup and neighbour frame from the tile's CONTENT, and every launch shape of a window -- batched, single,
         // HALF tail, accumulate-only, temporal -- carries both forms, so a pixel's bits do not depend on the launch.  (In the opaque
         // form the 0.001 is added after the weights instead of before them: the last bit of normWeight, nothing else.)

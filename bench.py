@@ -1021,6 +1021,42 @@ def main():
 
         guarded("pipeline_k2", extra_pipeline_k2)
 
+        def extra_multiframe():
+            if rank == 0 and world == 1:
+                # The reference's literal multi-frame mode with copy/compute overlap (mid_nlm_multiframe = RecordCommandsOfOverlappingNLM,
+                # src/main.cpp:889-989, loop :1539-1573: ONE target, nine neighbour frames streamed from the host, then normalize), with
+                # the frames in page-locked memory and in ordinary (pageable) memory -- the latter is what an integrator who keeps
+                # std::vector frames gets; the library bounces those through its own pinned buffers (csrc/hostcopy.cpp).
+                nfr = 9
+                hf = [f.cpu().numpy() for f in frames[:nfr]]
+                prm = mid.NlmParams(W, H, HPARAM, SEARCH[0], SEARCH[1], PATCH[0], PATCH[1], mid.FMT_RGBA32F)
+                pin = mid.PinnedFrames(ctx, hf)
+                pout = mid.PinnedFrames(ctx, 1, NPIX * 16)
+                pageable_out = np.empty((H, W, 4), np.float32)
+                try:
+                    def call(ptrs, target, out_ptr):
+                        t = (ctypes.c_float * 3)()
+                        t0 = time.perf_counter()
+                        rc = mid.lib.mid_nlm_multiframe(ctx.handle, ctypes.byref(prm), target, (ctypes.c_void_p * nfr)(*ptrs), nfr, out_ptr, 1, t)
+                        assert rc == 0, mid.lib.mid_last_error()
+                        return (time.perf_counter() - t0) * 1e3, t[1], t[2]
+                    res_m = {}
+                    for name, ptrs, out_ptr in (("pinned", list(pin.ptrs), pout.ptrs[0]),
+                                                ("pageable", [f.ctypes.data for f in hf], pageable_out.ctypes.data)):
+                        call(ptrs, ptrs[0], out_ptr)
+                        rows = sorted(call(ptrs, ptrs[0], out_ptr) for _ in range(3))
+                        wall, kern, copy = rows[1]
+                        res_m[name] = {"call_ms": round(wall, 3), "kernel_ms": round(kern, 3), "copy_ms": round(copy, 3)}
+                    same = np.array_equal(pout.array(0, (H, W, 4), np.float32), pageable_out)
+                    res_m["outputs_equal"] = bool(same)
+                    res_m["note"] = ("one 1080p RGBA32F target accumulated over 9 host frames (unfused mid_nlm_accum per frame + normalize, the reference's own "
+                                     "schedule) with the next frames' uploads overlapped; median of 3 calls; pageable = frames and result in ordinary memory")
+                    also["nlm_multiframe_overlap_9"] = res_m
+                finally:
+                    pin.free(); pout.free()
+
+        guarded("multiframe", extra_multiframe)
+
         def extra_image_io():
             if rank == 0 and world == 1:
                 # what the drop-in COMMAND spends per file around the GPU work -- the library's own PNG / EXR codecs

@@ -3,7 +3,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := image_denoising_filter_amd/csrc
 LIB     := image_denoising_filter_amd/libmi_denoise.so
-SRCS    := $(CSRC)/capi.cpp $(CSRC)/hostcopy.cpp $(CSRC)/markers.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/nlm_small.hip $(CSRC)/nlm_rt.hip $(CSRC)/nlm_rt4.hip $(CSRC)/pipeline.cpp $(CSRC)/sharded.cpp \
+SRCS    := $(CSRC)/capi.cpp $(CSRC)/hostcopy.cpp $(CSRC)/markers.cpp $(CSRC)/recording.cpp $(CSRC)/pointwise.hip $(CSRC)/bilateral.hip $(CSRC)/nlm.hip $(CSRC)/nlm_small.hip $(CSRC)/nlm_rt.hip $(CSRC)/nlm_rt4.hip $(CSRC)/pipeline.cpp $(CSRC)/sharded.cpp \
            $(CSRC)/codec/png.cpp $(CSRC)/codec/exr.cpp $(CSRC)/codec/piz.cpp $(CSRC)/codec/image_capi.cpp
 OBJS    := $(patsubst $(CSRC)/%,build/%.o,$(SRCS))
 HIPFLAGS := -x hip --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Iinclude

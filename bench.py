@@ -1057,6 +1057,68 @@ def main():
 
         guarded("multiframe", extra_multiframe)
 
+        def extra_graph():
+            if rank == 0 and world == 1:
+                # The reference records its dispatches once into a Vulkan command buffer and submits the recording
+                # (RecordCommandsOfExecuteNLM src/main.cpp:849-887, RunCommandBuffer :1078-1103); the HIP counterpart is a captured
+                # graph, offered as mid_record_begin / mid_record_end / mid_recording_submit (csrc/recording.cpp,
+                # tests/test_gpu_graph_capture.py).  Where does a graph pay?  The literal multi-frame mode -- clear, nine nonlocal.comp
+                # dispatches at the reference's window, normalize: 1 memset + 10 launches -- issued call by call against one replay,
+                # on a frame small enough to be launch-bound and on 1080p.
+                out = {}
+                for (hh, ww, reps) in ((128, 128, 200), (256, 256, 200), (H, W, 10)):
+                    fr = [torch.rand((hh, ww, 4), device=device, dtype=torch.float32) for _ in range(9)]
+                    for f in fr:
+                        f[..., 3] = 1.0
+                    Wb = torch.empty((hh, ww, 8), device=device, dtype=torch.float32)
+                    o = torch.empty((hh, ww, 4), device=device, dtype=torch.float32)
+                    prm = mid.NlmParams(ww, hh, HPARAM, -7, 7, -3, 3, mid.FMT_RGBA32F)
+                    pn = mid.NormalizeParams(ww, hh)
+                    gs = torch.cuda.Stream()
+
+                    def body(st):
+                        rc = mid.lib.mid_memset(ctx.handle, Wb.data_ptr(), 0, Wb.numel() * 4, st)
+                        assert rc == 0, mid.lib.mid_last_error()
+                        for f in fr:
+                            rc = mid.lib.mid_nlm_accum(ctx.handle, ctypes.byref(prm), fr[4].data_ptr(), f.data_ptr(), Wb.data_ptr(), st)
+                            assert rc == 0, mid.lib.mid_last_error()
+                        rc = mid.lib.mid_normalize(ctx.handle, ctypes.byref(pn), Wb.data_ptr(), o.data_ptr(), st)
+                        assert rc == 0, mid.lib.mid_last_error()
+                    torch.cuda.synchronize()
+                    body(gs.cuda_stream)
+                    gs.synchronize()
+                    want = o.clone()
+                    with ctx.record(gs.cuda_stream) as rec:            # mid_record_begin ... mid_record_end (csrc/recording.cpp)
+                        body(gs.cuda_stream)
+                    o.zero_()
+                    torch.cuda.synchronize()
+                    rec.submit(gs.cuda_stream)
+                    torch.cuda.synchronize()
+                    same = bool(torch.equal(o, want))
+
+                    def timed(fn):
+                        fn(); torch.cuda.synchronize()
+                        ts = []
+                        for _ in range(3):
+                            t0 = time.perf_counter()
+                            for _ in range(reps):
+                                fn()
+                            torch.cuda.synchronize()
+                            ts.append((time.perf_counter() - t0) / reps * 1e3)
+                        return sorted(ts)[1]
+
+                    t_call, t_graph = timed(lambda: body(gs.cuda_stream)), timed(lambda: rec.submit(gs.cuda_stream))
+                    out[f"{ww}x{hh}"] = {"by_call_ms": round(t_call, 4), "recording_submit_ms": round(t_graph, 4),
+                                         "ratio": round(t_call / t_graph, 3), "outputs_equal": same, "graph_nodes": rec.info()[0]}
+                    rec.close()
+                out["note"] = ("the reference's literal multi-frame sequence (1 memset + 9 mid_nlm_accum at [-7,7)/[-3,3) + mid_normalize) per target frame, issued "
+                               "through the C-ABI call by call (ctypes) against one mid_recording_submit of the recorded calls (a captured hipGraph: the counterpart of "
+                               "the reference's recorded command buffers); median of 3 timed loops; a recording pays where the sequence is launch-bound "
+                               "(small frames), not at 1080p; the same from compiled host code: profiles/r06_recording_replay.txt")
+                also["graph_replay_literal_nlm"] = out
+
+        guarded("graph", extra_graph)
+
         def extra_image_io():
             if rank == 0 and world == 1:
                 # what the drop-in COMMAND spends per file around the GPU work -- the library's own PNG / EXR codecs

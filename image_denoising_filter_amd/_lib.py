@@ -126,6 +126,11 @@ _SIGNATURES = {
     "mid_image_free_pinned": (ctypes.c_int, [_P, ctypes.POINTER(Image)]),
     "mid_image_save": (ctypes.c_int, [ctypes.c_char_p, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "mid_image_threads": (ctypes.c_int, [ctypes.c_int]),
+    "mid_record_begin": (ctypes.c_int, [_P, _P]),
+    "mid_record_end": (ctypes.c_int, [_P, _P, c_void_pp]),
+    "mid_recording_submit": (ctypes.c_int, [_P, _P]),
+    "mid_recording_info": (ctypes.c_int, [_P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "mid_recording_destroy": (ctypes.c_int, [_P]),
     "mid_timer_create": (ctypes.c_int, [_P, c_void_pp]),
     "mid_timer_destroy": (ctypes.c_int, [_P]),
     "mid_timer_tick": (ctypes.c_int, [_P, _P]),

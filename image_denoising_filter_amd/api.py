@@ -179,6 +179,12 @@ class Context:
         _check(lib.mid_stream_sync(self.handle, stream), "mid_stream_sync")
 
     # ---- raw (device pointer) operators: what bench.py and the pipeline use ------------------
+    def record(self, stream=None):
+        """`with ctx.record(stream) as rec:` -- the kernel-level calls issued on `stream` inside the block are RECORDED instead of executed
+        (vkBeginCommandBuffer ... vkEndCommandBuffer, src/main.cpp:791/846); afterwards `rec.submit(stream)` runs the sequence
+        (vkQueueSubmit, :1091) as often as needed."""
+        return Recording(self, stream)
+
     def bilateral_dev(self, in_ptr, out_ptr, w, h, radius, sigma_s, sigma_c, layout, fmt, stream=None):
         p = BilateralParams(w, h, sigma_s, sigma_c, radius, layout, fmt)
         _check(lib.mid_bilateral(self.handle, ctypes.byref(p), in_ptr, out_ptr, stream), "mid_bilateral")
@@ -357,6 +363,48 @@ class Context:
                 hin.free()
             if hout is not None:
                 hout.free()
+
+
+class Recording:
+    """A recorded sequence of kernel-level calls (mid_record_begin / mid_record_end / mid_recording_submit, csrc/recording.cpp)."""
+
+    def __init__(self, ctx, stream=None):
+        self.ctx, self.stream, self.handle = ctx, stream, None
+
+    def __enter__(self):
+        _check(lib.mid_record_begin(self.ctx.handle, self.stream), "mid_record_begin")
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        h = ctypes.c_void_p()
+        rc = lib.mid_record_end(self.ctx.handle, self.stream, ctypes.byref(h))      # (always: the stream must leave capture mode)
+        if exc_type is None:
+            _check(rc, "mid_record_end")
+            self.handle = h
+        elif rc == 0:
+            lib.mid_recording_destroy(h)
+        return False
+
+    def submit(self, stream=None):
+        if self.handle is None:
+            raise ValueError("the recording was not completed")
+        _check(lib.mid_recording_submit(self.handle, stream), "mid_recording_submit")
+
+    def info(self):
+        n, k = ctypes.c_int(), ctypes.c_int()
+        _check(lib.mid_recording_info(self.handle, ctypes.byref(n), ctypes.byref(k)), "mid_recording_info")
+        return n.value, k.value
+
+    def close(self):
+        if self.handle is not None:
+            lib.mid_recording_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 class PinnedFrames:

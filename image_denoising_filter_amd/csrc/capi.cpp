@@ -189,6 +189,7 @@ extern "C" int mid_memset(mid_ctx *ctx, void *dst, int value, size_t bytes, void
     Bind b(ctx, stream);
     if (b.rc) return b.rc;
     MID_REQUIRE(dst, "memset: NULL pointer");
+    if (stream_is_recording(b.s)) return fill_bytes(ctx, dst, value, bytes, b.s);     // (a captured hipMemsetAsync misbehaves: pointwise.hip)
     MID_HIP(hipMemsetAsync(dst, value, bytes, b.s));
     return MID_OK;
 }
@@ -197,6 +198,7 @@ extern "C" int mid_stream_sync(mid_ctx *ctx, void *stream)
 {
     Bind b(ctx, stream);
     if (b.rc) return b.rc;
+    if (int rc = refuse_if_recording(b.s, "mid_stream_sync (a host-side wait)")) return rc;
     MID_HIP(hipStreamSynchronize(b.s));
     return MID_OK;
 }
@@ -235,6 +237,7 @@ extern "C" int mid_timer_tick(mid_timer *t, void *stream)
     MID_REQUIRE(t, "timer_tick: NULL timer");
     Bind b(t->ctx, stream);
     if (b.rc) return b.rc;
+    if (int rc = refuse_if_recording(b.s, "mid_timer_tick (its event is read back by the host)")) return rc;
     MID_HIP(hipEventRecord(t->a, b.s));
     return MID_OK;
 }
@@ -244,6 +247,7 @@ extern "C" int mid_timer_tock(mid_timer *t, void *stream)
     MID_REQUIRE(t, "timer_tock: NULL timer");
     Bind b(t->ctx, stream);
     if (b.rc) return b.rc;
+    if (int rc = refuse_if_recording(b.s, "mid_timer_tock (its event is read back by the host)")) return rc;
     MID_HIP(hipEventRecord(t->b, b.s));
     return MID_OK;
 }

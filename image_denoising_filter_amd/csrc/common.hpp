@@ -77,6 +77,19 @@ struct Bind {
 
 inline unsigned cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
+// Entry points that wait on the host, allocate, or drive several streams cannot be part of a recording (csrc/recording.cpp: a stream
+// between mid_record_begin and mid_record_end is in HIP's capture mode): they refuse with a message instead of leaving an invalidated
+// capture behind.
+inline int refuse_if_recording(hipStream_t s, const char *what)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return MID_OK; }
+    if (st != hipStreamCaptureStatusNone)
+        return set_error(MID_ERR_INVALID, "%s cannot be part of a recording (mid_record_begin is open on this stream): only the calls that "
+                         "enqueue on ONE stream without waiting can -- kernels, mid_memset, copies from / to page-locked memory", what);
+    return MID_OK;
+}
+
 // Frees what the frame pipeline keeps in the context (pipeline.cpp); the context's streams must be idle.
 void pipe_cache_release(mid_ctx *ctx);
 
@@ -88,6 +101,15 @@ bool host_is_pinned(const void *p, size_t bytes);
 int copy_h2d(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t s);
 int copy_d2h(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t s);
 void bounce_release(mid_ctx *ctx);     // waits for the last chunks and frees both bounce sets
+
+// memset as a kernel launch (pointwise.hip): what mid_memset enqueues while its stream records -- see there why.
+int fill_bytes(mid_ctx *ctx, void *dst, int value, size_t bytes, hipStream_t s);
+inline bool stream_is_recording(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
 
 // mid_nlm_temporal with the output format as an argument: out_u8 != 0 writes RGBA8 frames (pack_rgba8 of the
 // normalized pixel) instead of float4 ones -- used by the frame pipeline's u8 variant, not exported.

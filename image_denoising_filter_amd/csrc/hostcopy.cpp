@@ -106,6 +106,7 @@ int copy_h2d(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t
         MID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
         return MID_OK;
     }
+    if (int rc = refuse_if_recording(s, "a copy from pageable host memory (bounced with host-side waits; page-lock it: mid_alloc_host / mid_host_register)")) return rc;
     mid_bounce &b = ctx->bounce_up;
     std::lock_guard<std::mutex> lock(b.mu);
     if (int rc = bounce_prepare(b)) return rc;
@@ -130,6 +131,7 @@ int copy_d2h(mid_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t
         MID_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
         return MID_OK;
     }
+    if (int rc = refuse_if_recording(s, "a copy to pageable host memory (bounced with host-side waits; page-lock it: mid_alloc_host / mid_host_register)")) return rc;
     mid_bounce &b = ctx->bounce_down;
     std::lock_guard<std::mutex> lock(b.mu);
     if (int rc = bounce_prepare(b)) return rc;

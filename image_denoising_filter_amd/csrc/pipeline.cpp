@@ -99,6 +99,7 @@ static int sequence_impl(mid_ctx *ctx, const mid_nlm_params *p, const void *cons
 {
     Bind b(ctx, nullptr);
     if (b.rc) return b.rc;
+    if (int rc = refuse_if_recording(ctx->compute, "mid_sequence_nlm (four streams, host-side waits)")) return rc;
     MID_REQUIRE(p && host_frames && host_out, "sequence_nlm: NULL argument");
     MID_REQUIRE(n >= 1 && k >= 0 && 2 * k + 2 <= kMaxFrames, "sequence_nlm: bad n=%d k=%d", n, k);
     MID_REQUIRE(first >= 0 && count >= 1 && first + count <= n, "sequence_nlm: bad range first=%d count=%d n=%d", first, count, n);
@@ -381,6 +382,7 @@ extern "C" int mid_nlm_multiframe(mid_ctx *ctx, const mid_nlm_params *p, const v
 {
     Bind b(ctx, nullptr);
     if (b.rc) return b.rc;
+    if (int rc = refuse_if_recording(ctx->compute, "mid_nlm_multiframe (three streams, host-side waits)")) return rc;
     MID_REQUIRE(p && host_target && host_frames && host_out, "nlm_multiframe: NULL argument");
     MID_REQUIRE(n >= 1 && p->width > 0 && p->height > 0, "nlm_multiframe: bad n=%d or size", n);
     for (int i = 0; i < n; ++i) MID_REQUIRE(host_frames[i], "nlm_multiframe: frame %d is NULL", i);

@@ -54,11 +54,38 @@ __global__ __launch_bounds__(256) void pack_tail_kernel(const float *in, uint8_t
     if (i < n) out[i] = (uint8_t)pack1(in[i]);
 }
 
+// mid_memset INSIDE A RECORDING (csrc/recording.cpp).  A hipMemsetAsync captured into a graph came back wrong on this runtime (HIP 7.0.51831,
+// ROCm 7.2 image): the reference's literal multi-frame sequence recorded as [memset, 5 x nlm_accum, normalize] replayed with the
+// WeightInfo buffer "cleared" to a pattern of stale host words (tests/test_gpu_graph_capture.py found it; LABNOTES R6.10) -- the memset node
+// keeps a reference to something that is gone by the time the graph runs.  Kernel nodes carry their arguments by value, so while a
+// stream records the clear is this kernel: 16 B per lane, grid-stride, then the unaligned head / tail bytes one per lane.
+__global__ __launch_bounds__(256) void fill_kernel(uint8_t *dst, uint32_t word, size_t head, size_t n16, size_t tail)
+{
+    uint4 *body = (uint4 *)(dst + head);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) body[i] = make_uint4(word, word, word, word);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) dst[threadIdx.x] = (uint8_t)word;
+        if (threadIdx.x < tail) dst[head + n16 * 16 + threadIdx.x] = (uint8_t)word;
+    }
+}
+
 static unsigned stream_grid(mid_ctx *ctx, size_t n)
 {
     // (8 workgroups per CU; 4, 16, 32 and "one pixel per thread" measure the same: profiles/r05_ab_stream_grid_cap.txt)
     const size_t want = (n + 255) / 256, cap = (size_t)ctx->cu_count * 8;
     return (unsigned)(want < cap ? (want ? want : 1) : cap);
+}
+
+int fill_bytes(mid_ctx *ctx, void *dst, int value, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0) return MID_OK;
+    const uint32_t word = 0x01010101u * (uint32_t)(value & 0xff);
+    size_t head = (16 - ((uintptr_t)dst & 15u)) & 15u;
+    if (head > bytes) head = bytes;
+    const size_t n16 = (bytes - head) / 16, tail = bytes - head - n16 * 16;
+    hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(ctx, n16)), dim3(256), 0, s, (uint8_t *)dst, word, head, n16, tail);
+    MID_HIP(hipGetLastError());
+    return MID_OK;
 }
 
 }  // namespace mid

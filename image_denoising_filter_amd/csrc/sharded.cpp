@@ -418,6 +418,7 @@ extern "C" int mid_comm_loopback(mid_comm *c, const void *src, void *dst, size_t
     MID_REQUIRE(!c->aborted, "comm_loopback: the communicator was aborted");
     Bind b(c->ctx, stream);
     if (b.rc) return b.rc;
+    if (int rc = refuse_if_recording(b.s, "mid_comm_loopback (RCCL on the exchange stream)")) return rc;
     c->have_loop = false;
     MID_HIP(hipEventRecord(c->lq, b.s));
     MID_HIP(hipStreamWaitEvent(c->xs, c->lq, 0));
@@ -456,6 +457,7 @@ extern "C" int mid_nlm_temporal_sharded(mid_comm *c, const mid_nlm_params *p, co
     MID_REQUIRE(!c->aborted, "nlm_temporal_sharded: the communicator was aborted");
     Bind b(c->ctx, stream);
     if (b.rc) return b.rc;
+    if (int rc = refuse_if_recording(b.s, "mid_nlm_temporal_sharded (RCCL, exchange and boundary streams)")) return rc;
     // Stream rule.  The receive buffers, e0/e1 and the exchange stream are reused from call to call, ordered behind the
     // previous call's launches only through the stream both calls are issued on.  A call on ANOTHER stream is accepted
     // only once the previous call has finished (the caller synchronised its stream, or the work simply is done);

@@ -148,6 +148,38 @@ int mid_memcpy_d2h(mid_ctx *ctx, void *dst_host, const void *src, size_t bytes, 
 int mid_memset(mid_ctx *ctx, void *dst, int value, size_t bytes, void *stream);                 /* the reference never clears its weight buffer; callers of *_accum must */
 int mid_stream_sync(mid_ctx *ctx, void *stream);                     /* vkWaitForFences, src/main.cpp:1092 */
 
+/* ---- recorded command sequences ---------------------------------------------------------
+ * The reference works on RECORDED command buffers: every RecordCommandsOf* brackets its dispatches, barriers and copies with
+ * vkBeginCommandBuffer / vkEndCommandBuffer (src/main.cpp:791/846, 855/886, 895/988, 996/1075) and RunCommandBuffer submits the
+ * recording (vkQueueSubmit, :1078-1103); it records anew before each submission.  Here a sequence is recorded ONCE and submitted
+ * as often as needed -- the HIP counterpart of a command buffer is a captured graph (csrc/recording.cpp):
+ *   mid_record_begin(ctx, stream)          vkBeginCommandBuffer: `stream` (NULL = the context's compute stream) stops executing
+ *                                          and records instead;
+ *   ... kernel-level calls on that stream  mid_bilateral*, mid_nlm_accum, mid_nlm_temporal, mid_normalize, mid_pack_u8,
+ *                                          mid_unpack_u8, mid_memset, mid_memcpy_* from / to PAGE-LOCKED memory: everything that only
+ *                                          enqueues on the one stream.  Arguments are taken as they are at record time: the same
+ *                                          buffers are read and written by every submission (like bound descriptors), their
+ *                                          CONTENT is whatever it is when the submission runs;
+ *   mid_record_end(ctx, stream, &rec)      vkEndCommandBuffer; the stream executes again;
+ *   mid_recording_submit(rec, stream)      vkQueueSubmit: asynchronous on `stream` (any stream of the context's device), ordered
+ *                                          like one launch; the same recording must not be in flight twice at the same time;
+ *   mid_recording_destroy(rec)             after its last submission has completed.
+ * One runtime call per submission instead of one per dispatch: the reference's literal multi-frame sequence (clear, nine
+ * nonlocal.comp dispatches, normalize) on a 128x128 / 256x256 frame -- where it is launch-bound -- see bench.py
+ * also.graph_replay_literal_nlm and profiles/r06_recording_replay.txt; at 1080p the kernels dominate and a recording changes nothing.
+ * Refused while a stream records (MID_ERR_INVALID, the recording stays valid): calls that wait on the host, drive several streams or
+ * bounce pageable memory -- mid_stream_sync, mid_timer_tick/tock, mid_sequence_nlm*, mid_nlm_multiframe, mid_nlm_temporal_sharded,
+ * mid_comm_loopback, copies from / to pageable host memory.  Do not allocate or free (mid_alloc*, mid_free*, mid_host_register) on the
+ * recording thread between begin and end: the runtime fails such calls and invalidates the recording (mid_record_end then reports
+ * it).  The capture is thread-local: other threads keep using their own streams meanwhile.  A kernel's first ever launch may be
+ * inside a recording (raising its LDS limit is not a stream operation). */
+typedef struct mid_recording mid_recording;
+int mid_record_begin(mid_ctx *ctx, void *stream);
+int mid_record_end(mid_ctx *ctx, void *stream, mid_recording **out);
+int mid_recording_submit(mid_recording *rec, void *stream);
+int mid_recording_info(mid_recording *rec, int *n_nodes /* graph nodes */, int *n_kernels /* of them kernel launches */);
+int mid_recording_destroy(mid_recording *rec);
+
 /* ---- a1/a2: plain bilateral -----------------------------------------------------------
  * Replaces the dispatch of shaders/bialteral.comp / bialteral_linear.comp recorded by
  * RecordCommandsOfExecuteAndTransfer(normKernel=false), src/main.cpp:785-847: bindings

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 name, src_rel, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
-ALL = "capi.cpp hostcopy.cpp markers.cpp pointwise.hip bilateral.hip nlm.hip nlm_small.hip nlm_rt.hip nlm_rt4.hip pipeline.cpp sharded.cpp codec/png.cpp codec/exr.cpp codec/piz.cpp codec/image_capi.cpp".split()
+ALL = "capi.cpp hostcopy.cpp markers.cpp recording.cpp pointwise.hip bilateral.hip nlm.hip nlm_small.hip nlm_rt.hip nlm_rt4.hip pipeline.cpp sharded.cpp codec/png.cpp codec/exr.cpp codec/piz.cpp codec/image_capi.cpp".split()
 assert src_rel in ALL, src_rel
 base = "-x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function".split()
 if src_rel.startswith("nlm") and "--default-sched" not in extra:

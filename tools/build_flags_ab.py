@@ -15,7 +15,7 @@ SETS = {
     8: ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
 }
 objs = [os.path.join(ROOT, "build", o) for o in
-        "capi.cpp.o pointwise.hip.o bilateral.hip.o nlm_rt.hip.o nlm_rt4.hip.o pipeline.cpp.o sharded.cpp.o codec/png.cpp.o codec/exr.cpp.o codec/piz.cpp.o codec/image_capi.cpp.o".split()]
+        "capi.cpp.o hostcopy.cpp.o markers.cpp.o recording.cpp.o nlm_small.hip.o pointwise.hip.o bilateral.hip.o nlm_rt.hip.o nlm_rt4.hip.o pipeline.cpp.o sharded.cpp.o codec/png.cpp.o codec/exr.cpp.o codec/piz.cpp.o codec/image_capi.cpp.o".split()]
 base = "-x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize".split()
 d = os.path.join(ROOT, "build", "abl")
 os.makedirs(d, exist_ok=True)

@@ -13,6 +13,7 @@ extern "C" int mid_nlm_temporal(mid_ctx *, const mid_nlm_params *, const void *c
 extern "C" int mid_nlm_accum(mid_ctx *, const mid_nlm_params *, const void *, const void *, mid_weightinfo *, void *) { return MID_ERR_UNSUPPORTED; }
 extern "C" int mid_normalize(mid_ctx *, const mid_normalize_params *, const mid_weightinfo *, mid_pixel *, void *) { return MID_ERR_UNSUPPORTED; }
 int mid::nlm_temporal_out(mid_ctx *, const mid_nlm_params *, const void *const *, int, int, int, int, void *const *, int, void *, int) { return MID_ERR_UNSUPPORTED; }
+int mid::fill_bytes(mid_ctx *, void *, int, size_t, hipStream_t) { return MID_ERR_UNSUPPORTED; }      // (pointwise.hip: kernels are not part of this CPU build)
 
 int main()
 {

@@ -189,7 +189,7 @@ extern "C" int mid_memset(mid_ctx *ctx, void *dst, int value, size_t bytes, void
     Bind b(ctx, stream);
     if (b.rc) return b.rc;
     MID_REQUIRE(dst, "memset: NULL pointer");
-    if (stream_is_recording(b.s)) return fill_bytes(ctx, dst, value, bytes, b.s);     // (a captured hipMemsetAsync misbehaves: pointwise.hip)
+    if (stream_is_recording(b.s)) return fill_bytes(ctx, dst, value, bytes, b.s);     // (a kernel node instead of a memset node: pointwise.hip says why)
     MID_HIP(hipMemsetAsync(dst, value, bytes, b.s));
     return MID_OK;
 }

@@ -54,11 +54,13 @@ __global__ __launch_bounds__(256) void pack_tail_kernel(const float *in, uint8_t
     if (i < n) out[i] = (uint8_t)pack1(in[i]);
 }
 
-// mid_memset INSIDE A RECORDING (csrc/recording.cpp).  A hipMemsetAsync captured into a graph came back wrong on this runtime (HIP 7.0.51831,
-// ROCm 7.2 image): the reference's literal multi-frame sequence recorded as [memset, 5 x nlm_accum, normalize] replayed with the
-// WeightInfo buffer "cleared" to a pattern of stale host words (tests/test_gpu_graph_capture.py found it; LABNOTES R6.10) -- the memset node
-// keeps a reference to something that is gone by the time the graph runs.  Kernel nodes carry their arguments by value, so while a
-// stream records the clear is this kernel: 16 B per lane, grid-stride, then the unaligned head / tail bytes one per lane.
+// mid_memset INSIDE A RECORDING (csrc/recording.cpp) is this kernel, not a captured hipMemsetAsync.  In the GPU suite the reference's literal
+// multi-frame sequence recorded as [hipMemsetAsync, 5 x nlm_accum, normalize] replayed -- in 7 of 7 runs, for the [-7,7)/[-3,3) window,
+// on a created stream and on the context's own -- with the WeightInfo buffer holding address-like words instead of zeros where the memset
+// node should have cleared it (HIP 7.0.51831 as bundled with torch; the same calls inside a torch-owned capture, and the 21x21 window,
+// came out right).  A stand-alone probe of memset (+ kernel) graphs does NOT reproduce it (tools/probe_graph_memset.hip, either runtime),
+// so the cause is not established (LABNOTES R6.10); what is established is that a recording made of kernel and copy nodes only
+// replays right everywhere it was tried.  16 B per lane, grid-stride, then the unaligned head / tail bytes one per lane.
 __global__ __launch_bounds__(256) void fill_kernel(uint8_t *dst, uint32_t word, size_t head, size_t n16, size_t tail)
 {
     uint4 *body = (uint4 *)(dst + head);

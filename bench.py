@@ -1028,7 +1028,7 @@ def main():
                 # the frames in page-locked memory and in ordinary (pageable) memory -- the latter is what an integrator who keeps
                 # std::vector frames gets; the library bounces those through its own pinned buffers (csrc/hostcopy.cpp).
                 nfr = 9
-                hf = [f.cpu().numpy() for f in frames[:nfr]]
+                hf = [frames[i % len(frames)].cpu().numpy() for i in range(nfr)]      # (--frames may be smaller than nine)
                 prm = mid.NlmParams(W, H, HPARAM, SEARCH[0], SEARCH[1], PATCH[0], PATCH[1], mid.FMT_RGBA32F)
                 pin = mid.PinnedFrames(ctx, hf)
                 pout = mid.PinnedFrames(ctx, 1, NPIX * 16)
@@ -1113,8 +1113,9 @@ def main():
                     rec.close()
                 out["note"] = ("the reference's literal multi-frame sequence (1 memset + 9 mid_nlm_accum at [-7,7)/[-3,3) + mid_normalize) per target frame, issued "
                                "through the C-ABI call by call (ctypes) against one mid_recording_submit of the recorded calls (a captured hipGraph: the counterpart of "
-                               "the reference's recorded command buffers); median of 3 timed loops; a recording pays where the sequence is launch-bound "
-                               "(small frames), not at 1080p; the same from compiled host code: profiles/r06_recording_replay.txt")
+                               "the reference's recorded command buffers); median of 3 timed loops.  Same bytes, NO gain at any size: the nine accumulates depend on each other and a "
+                               "tile's 196 offsets take ~45 us whatever the frame, so the chain is 0.46 ms from 64x64 to 512x512 (the fused mid_nlm_temporal is the answer "
+                               "to that, not a graph); from compiled host code, also for 28 short launches (4 us per launch either way): profiles/r06_recording_replay.txt")
                 also["graph_replay_literal_nlm"] = out
 
         guarded("graph", extra_graph)

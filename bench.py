@@ -1062,9 +1062,9 @@ def main():
                 # The reference records its dispatches once into a Vulkan command buffer and submits the recording
                 # (RecordCommandsOfExecuteNLM src/main.cpp:849-887, RunCommandBuffer :1078-1103); the HIP counterpart is a captured
                 # graph, offered as mid_record_begin / mid_record_end / mid_recording_submit (csrc/recording.cpp,
-                # tests/test_gpu_graph_capture.py).  Where does a graph pay?  The literal multi-frame mode -- clear, nine nonlocal.comp
-                # dispatches at the reference's window, normalize: 1 memset + 10 launches -- issued call by call against one replay,
-                # on a frame small enough to be launch-bound and on 1080p.
+                # tests/test_gpu_graph_capture.py).  Does a recording pay?  The literal multi-frame mode -- clear, nine nonlocal.comp
+                # dispatches at the reference's window, normalize: 11 launches -- issued call by call against one submission, on small
+                # frames and on 1080p (LABNOTES R6.10: it does not; the line keeps the evidence).
                 out = {}
                 for (hh, ww, reps) in ((128, 128, 200), (256, 256, 200), (H, W, 10)):
                     fr = [torch.rand((hh, ww, 4), device=device, dtype=torch.float32) for _ in range(9)]

@@ -54,13 +54,14 @@ __global__ __launch_bounds__(256) void pack_tail_kernel(const float *in, uint8_t
     if (i < n) out[i] = (uint8_t)pack1(in[i]);
 }
 
-// mid_memset INSIDE A RECORDING (csrc/recording.cpp) is this kernel, not a captured hipMemsetAsync.  In the GPU suite the reference's literal
-// multi-frame sequence recorded as [hipMemsetAsync, 5 x nlm_accum, normalize] replayed -- in 7 of 7 runs, for the [-7,7)/[-3,3) window,
-// on a created stream and on the context's own -- with the WeightInfo buffer holding address-like words instead of zeros where the memset
-// node should have cleared it (HIP 7.0.51831 as bundled with torch; the same calls inside a torch-owned capture, and the 21x21 window,
-// came out right).  A stand-alone probe of memset (+ kernel) graphs does NOT reproduce it (tools/probe_graph_memset.hip, either runtime),
-// so the cause is not established (LABNOTES R6.10); what is established is that a recording made of kernel and copy nodes only
-// replays right everywhere it was tried.  16 B per lane, grid-stride, then the unaligned head / tail bytes one per lane.
+// mid_memset INSIDE A RECORDING (csrc/recording.cpp) is this kernel, not a captured hipMemsetAsync.  With one build of the library the
+// reference's literal multi-frame sequence recorded as [hipMemsetAsync, 5 x nlm_accum, normalize] replayed -- 7 of 7 runs, [-7,7)/[-3,3)
+// window, on a created stream and on the context's own -- with the WeightInfo buffer FILLED WITH A PERIODIC PATTERN OF ADDRESS-LIKE WORDS
+// where the memset node (the runtime's __amd_rocclr_fillBufferAligned) should have written zeros: a fill whose pattern had been overwritten
+// (HIP 7.0.51831 as bundled with torch).  It depends on the process's memory layout: the next build with the memset node restored passed,
+// and a stand-alone probe of memset (+ kernel) graphs never shows it (tools/probe_graph_memset.hip, either runtime; LABNOTES R6.10).  A
+// kernel node carries its arguments by value, so the clear of a recording is a launch of ours: 16 B per lane, grid-stride, then the
+// unaligned head / tail bytes one per lane.
 __global__ __launch_bounds__(256) void fill_kernel(uint8_t *dst, uint32_t word, size_t head, size_t n16, size_t tail)
 {
     uint4 *body = (uint4 *)(dst + head);

@@ -56,6 +56,17 @@ int main()
             CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
             if (check("  launch after eager memsets / copies on the stream:", W, n, (float)adds)) return 1;
         }
+        // many eager launches with large argument blocks between two launches of the graph: is anything the memset node needs kept in a ring they recycle?
+        if (mode == 6 || mode == 14) {
+            for (int burst : {10, 100, 1000, 10000, 100000}) {
+                Big b{}; b.p = other; b.n = 256; for (int j = 0; j < 192; ++j) b.table[j] = (const void *)(other + j);
+                for (int i = 0; i < burst; ++i) { hipLaunchKernelGGL(add1big, dim3(1), dim3(256), 0, s, b); if ((i & 1023) == 1023) CK(hipStreamSynchronize(s)); }
+                hipLaunchKernelGGL(fill, dim3(64), dim3(256), 0, s, W, n, 7.0f); CK(hipStreamSynchronize(s));
+                CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+                char what[96]; snprintf(what, sizeof what, "  launch after %d eager launches with 1.5 KB of arguments:", burst);
+                if (check(what, W, n, (float)adds)) return 1;
+            }
+        }
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
     return 0;

@@ -1062,7 +1062,7 @@ def main():
                 # The reference records its dispatches once into a Vulkan command buffer and submits the recording
                 # (RecordCommandsOfExecuteNLM src/main.cpp:849-887, RunCommandBuffer :1078-1103); the HIP counterpart is a captured
                 # graph, offered as mid_record_begin / mid_record_end / mid_recording_submit (csrc/recording.cpp,
-                # tests/test_gpu_graph_capture.py).  Does a recording pay?  The literal multi-frame mode -- clear, nine nonlocal.comp
+                # tests/test_gpu_z_recording.py).  Does a recording pay?  The literal multi-frame mode -- clear, nine nonlocal.comp
                 # dispatches at the reference's window, normalize: 11 launches -- issued call by call against one submission, on small
                 # frames and on 1080p (LABNOTES R6.10: it does not; the line keeps the evidence).
                 out = {}

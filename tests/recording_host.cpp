@@ -1,4 +1,4 @@
-// recording_host.cpp -- TEST RESOURCE (tests/test_gpu_graph_capture.py, tools/recording_replay.sh): a compiled host of the recording
+// recording_host.cpp -- TEST RESOURCE (tests/test_gpu_z_recording.py, tools/recording_replay.sh): a compiled host of the recording
 // API (no HIP header: the C-ABI only).
 //   recording_host <w> <h> <frames> <repetitions> <out.raw> [ldr]
 // ldr: instead of the NLM sequence, the PNG path of a single-image mode per frame -- mid_unpack_u8, mid_bilateral (r = 4), mid_pack_u8 --

@@ -9,6 +9,8 @@ modes: a submitted recording writes the bits the same calls write when issued on
 capture the CALLER owns (torch.cuda.CUDAGraph = hipStreamBeginCapture in global mode: any hipMalloc / synchronisation inside would
 fail it); calls that cannot be recorded are refused with a message and leave the recording valid; a C++ host records COLD (every
 kernel's first launch inside the recording) and gets the same bytes.
+(The file name sorts last among the GPU suites on purpose: the driver runs them with -x, and graph capture is the one place where this
+round met a runtime misbehaviour that comes and goes with the memory layout -- LABNOTES R6.10.)
 """
 import ctypes
 

@@ -1,6 +1,6 @@
 // probe_graph_memset.hip -- development probe behind LABNOTES R6.10: does a hipMemsetAsync captured into a graph clear its buffer on every launch?
 //   hipcc --offload-arch=gfx950 -O2 tools/probe_graph_memset.hip -o /tmp/probe_graph_memset && /tmp/probe_graph_memset
-// Sequence of tests/test_gpu_graph_capture.py's first failure: capture [memset W], then eager work on the same stream (other memsets,
+// Sequence of tests/test_gpu_z_recording.py's first failure: capture [memset W], then eager work on the same stream (other memsets,
 // kernels, copies), then launch the graph and read W back.
 #include <hip/hip_runtime.h>
 #include <cstdio>

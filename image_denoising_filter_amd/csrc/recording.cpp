@@ -5,7 +5,8 @@
 // mid_record_begin puts the stream into capture mode, the kernel-level entry points of this library enqueue onto it as they always
 // do (they only launch kernels / async copies on the stream they are given: no allocation, no host-side wait, no second stream),
 // mid_record_end instantiates the graph, mid_recording_submit launches it: one runtime call per sequence instead of one per
-// dispatch, which is what counts where a sequence is launch-bound (small frames: bench.py also.graph_replay_literal_nlm).
+// dispatch.  Measured (profiles/r06_recording_replay.txt): same bytes, no faster than a stream of launches from compiled code on
+// this runtime (about 4 us per launch either way) -- the API is there for the program shape the reference has, not as a speed-up.
 // The capture is thread-local (hipStreamCaptureModeThreadLocal): other threads of the process keep working on their own streams.
 #include "common.hpp"
 

@@ -164,9 +164,11 @@ int mid_stream_sync(mid_ctx *ctx, void *stream);                     /* vkWaitFo
  *   mid_recording_submit(rec, stream)      vkQueueSubmit: asynchronous on `stream` (any stream of the context's device), ordered
  *                                          like one launch; the same recording must not be in flight twice at the same time;
  *   mid_recording_destroy(rec)             after its last submission has completed.
- * One runtime call per submission instead of one per dispatch: the reference's literal multi-frame sequence (clear, nine
- * nonlocal.comp dispatches, normalize) on a 128x128 / 256x256 frame -- where it is launch-bound -- see bench.py
- * also.graph_replay_literal_nlm and profiles/r06_recording_replay.txt; at 1080p the kernels dominate and a recording changes nothing.
+ * One runtime call per submission instead of one per dispatch.  Measured on MI355X (profiles/r06_recording_replay.txt, bench.py
+ * also.graph_replay_literal_nlm): the same bytes, and NOT faster than the calls issued one by one from compiled code -- about 4 us per
+ * launch either way, and the reference's literal multi-frame sequence is bound by its chain of dependent kernels at every frame size.
+ * A matter of program shape; for speed use the fused entry points (mid_nlm_temporal, mid_bilateral_batch, mid_bilateral_layers).
+ * mid_record_begin and mid_record_end of one recording are called on the same thread.
  * Refused while a stream records (MID_ERR_INVALID, the recording stays valid): calls that wait on the host, drive several streams or
  * bounce pageable memory -- mid_stream_sync, mid_timer_tick/tock, mid_sequence_nlm*, mid_nlm_multiframe, mid_nlm_temporal_sharded,
  * mid_comm_loopback, copies from / to pageable host memory.  Do not allocate or free (mid_alloc*, mid_free*, mid_host_register) on the

@@ -28,6 +28,9 @@ SRC = textwrap.dedent(r'''
         /* no context: every compute entry point refuses */
         if (mid_bilateral(NULL, &bp, NULL, NULL, NULL) != MID_ERR_INVALID) return 15;
         if (mid_nlm_accum(NULL, &np, NULL, NULL, NULL, NULL) != MID_ERR_INVALID) return 16;
+        { mid_recording *rec = NULL;        /* recorded command sequences: no context, no recording */
+          if (mid_record_begin(NULL, NULL) != MID_ERR_INVALID || mid_record_end(NULL, NULL, &rec) != MID_ERR_INVALID || rec != NULL) return 17;
+          if (mid_recording_submit(NULL, NULL) != MID_ERR_INVALID || mid_recording_destroy(NULL) != MID_OK) return 18; }
         puts("no device, refused");
         return 0;
     }

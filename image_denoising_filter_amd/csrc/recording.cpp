@@ -9,6 +9,7 @@
 // this runtime (about 4 us per launch either way) -- the API is there for the program shape the reference has, not as a speed-up.
 // The capture is thread-local (hipStreamCaptureModeThreadLocal): other threads of the process keep working on their own streams.
 #include "common.hpp"
+#include <new>
 
 struct mid_recording {
     mid_ctx *ctx;
@@ -48,17 +49,20 @@ extern "C" int mid_record_end(mid_ctx *ctx, void *stream, mid_recording **out)
         return set_error(MID_ERR_HIP, "record_end: the recording is invalid (%s): a call inside it failed or cannot be recorded",
                          e != hipSuccess ? hipGetErrorString(e) : "no graph");
     }
-    mid_recording *r = new mid_recording{ctx, graph, nullptr, 0, 0};
+    mid_recording *r = new (std::nothrow) mid_recording{ctx, graph, nullptr, 0, 0};
+    if (!r) { (void)hipGraphDestroy(graph); return set_error(MID_ERR_HIP, "record_end: out of host memory"); }
     size_t n = 0;
     if (hipGraphGetNodes(graph, nullptr, &n) == hipSuccess && n > 0) {
-        std::vector<hipGraphNode_t> nodes(n);
-        if (hipGraphGetNodes(graph, nodes.data(), &n) == hipSuccess) {
-            r->n_nodes = (int)n;
-            for (size_t i = 0; i < n; ++i) {
-                hipGraphNodeType t;
-                if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++r->n_kernels;
+        try {                                        // (no exception may cross the C ABI; the node counts are informational)
+            std::vector<hipGraphNode_t> nodes(n);
+            if (hipGraphGetNodes(graph, nodes.data(), &n) == hipSuccess) {
+                r->n_nodes = (int)n;
+                for (size_t i = 0; i < n; ++i) {
+                    hipGraphNodeType t;
+                    if (hipGraphNodeGetType(nodes[i], &t) == hipSuccess && t == hipGraphNodeTypeKernel) ++r->n_kernels;
+                }
             }
-        }
+        } catch (...) { r->n_nodes = r->n_kernels = 0; }
     }
     (void)hipGetLastError();
     e = hipGraphInstantiate(&r->exec, graph, nullptr, nullptr, 0);

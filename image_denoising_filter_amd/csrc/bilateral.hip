@@ -558,6 +558,7 @@ extern "C" int mid_bilateral_layers(mid_ctx *ctx, const mid_bilateral_params *p,
     if (b.rc) return b.rc;
     if (int rc = check_params(p, "bilateral_layers")) return rc;
     MID_REQUIRE(in && layers && out, "bilateral_layers: NULL pointer");
+    MID_REQUIRE((const void *)out != in, "bilateral_layers: out is the input image (in-place filtering is not supported)");
     MID_REQUIRE(p->layout == MID_LAYOUT_TEXTURE, "bilateral_layers: layers exist for the texture layout only");
     MID_REQUIRE(n_layers >= 0 && n_layers <= 16, "bilateral_layers: n_layers %d outside 0..16", n_layers);
     BilArgs a{};

@@ -24,6 +24,7 @@
 //
 // Out-of-image texels are vec4(0) for both images (LDS halo zero-filled).
 #include "nlm_strip.hpp"
+#include <unordered_set>
 
 namespace mid {
 
@@ -174,6 +175,19 @@ extern "C" int mid_nlm_temporal(mid_ctx *ctx, const mid_nlm_params *p, const voi
                                 int n_frames, int k, int first, int count, mid_pixel *const *out,
                                 void *stream)
 {
+    // Every output frame of a launch is computed concurrently from the input frames around it: an output that IS one of the sequence's
+    // frames (filtering in place, ping-pong tables shifted by a slot) would be overwritten while other workgroups still read it, and a
+    // buffer given twice would be written by two frames.  Refused here, like mid_bilateral_batch does (the library-internal callers of
+    // nlm_temporal_out -- the frame pipeline, the sharded call -- own their rings and slots).
+    if (frames && out && n_frames >= 1 && count >= 1 && first >= 0 && first + count <= n_frames) {
+        std::unordered_set<const void *> inputs(frames, frames + n_frames), outputs;
+        for (int t = 0; t < count; ++t) {
+            if (!out[t]) continue;                                                   // (reported as NULL below)
+            MID_REQUIRE(!inputs.count((const void *)out[t]),
+                        "nlm_temporal: out[%d] is also a frame of the sequence (in-place / aliased filtering is not supported)", t);
+            MID_REQUIRE(outputs.insert((const void *)out[t]).second, "nlm_temporal: out[%d] appears twice", t);
+        }
+    }
     return mid::nlm_temporal_out(ctx, p, frames, n_frames, k, first, count, (void *const *)out, 0, stream);
 }
 

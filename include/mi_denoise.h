@@ -220,6 +220,7 @@ int mid_bilateral_layers(mid_ctx *ctx, const mid_bilateral_params *p, const void
  * one launch (grid.z = output frame); k = 0 is independent single-frame NLM over a batch. */
 int mid_nlm_accum(mid_ctx *ctx, const mid_nlm_params *p, const void *target,
                   const void *neighbour, mid_weightinfo *W, void *stream);
+/* (mid_nlm_temporal: no aliasing -- an `out` buffer must not be a frame of the sequence nor appear twice: MID_ERR_INVALID, as for mid_bilateral_batch.) */
 int mid_nlm_temporal(mid_ctx *ctx, const mid_nlm_params *p,
                      const void *const *frames /* host array of n_frames device ptrs */,
                      int n_frames, int k, int first, int count,

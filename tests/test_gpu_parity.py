@@ -546,6 +546,31 @@ def test_bilateral_batch_argument_errors(ctx):
     ctx.sync()
 
 
+def test_nlm_temporal_and_layers_refuse_aliased_outputs(ctx):
+    """Every output frame of a launch is computed concurrently from the frames around it: an output that is a frame of the sequence (in place,
+    ping-pong tables shifted by a slot) or a buffer given twice is refused before anything is launched, like mid_bilateral_batch."""
+    import ctypes
+    img = np.zeros((8, 8, 4), np.float32)
+    fr = [ctx.upload(img) for _ in range(3)]
+    o = [ctx.alloc(8 * 8 * 16) for _ in range(3)]
+    p = mid.NlmParams(8, 8, 0.5, -7, 7, -3, 3, mid.FMT_RGBA32F)
+    frames = (ctypes.c_void_p * 3)(*[f.ptr for f in fr])
+
+    def call(outs, first=0, count=3, k=1):
+        return mid.lib.mid_nlm_temporal(ctx.handle, ctypes.byref(p), frames, 3, k, first, count, (ctypes.c_void_p * len(outs))(*outs), None)
+    assert call([fr[0].ptr, o[1].ptr, o[2].ptr]) == 1 and b"also a frame of the sequence" in mid.lib.mid_last_error()      # in place
+    assert call([fr[1].ptr], first=0, count=1) == 1                                     # out[0] is the NEXT frame: a shifted ping-pong table
+    assert call([o[0].ptr, o[0].ptr, o[2].ptr]) == 1 and b"appears twice" in mid.lib.mid_last_error()
+    assert call([o[0].ptr, o[1].ptr, o[2].ptr]) == 0
+    ctx.sync()
+    bp = mid.BilateralParams(8, 8, 2.0, 0.2, 4, 0, 0)
+    lay = ctx.upload(np.zeros((8, 8, 4), np.uint8))
+    tbl = (ctypes.c_void_p * 1)(lay.ptr)
+    assert mid.lib.mid_bilateral_layers(ctx.handle, ctypes.byref(bp), fr[0].ptr, tbl, 1, fr[0].ptr, None) == 1 and b"in-place" in mid.lib.mid_last_error()
+    assert mid.lib.mid_bilateral_layers(ctx.handle, ctypes.byref(bp), fr[0].ptr, tbl, 1, o[0].ptr, None) == 0
+    ctx.sync()
+
+
 def test_bilateral_batch_chunks_beyond_the_frame_table(ctx):
     """More frames than the by-value frame table holds (96): several launches, same bits."""
     rng = np.random.default_rng(811)

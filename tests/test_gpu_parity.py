@@ -569,6 +569,12 @@ def test_nlm_temporal_and_layers_refuse_aliased_outputs(ctx):
     assert mid.lib.mid_bilateral_layers(ctx.handle, ctypes.byref(bp), fr[0].ptr, tbl, 1, fr[0].ptr, None) == 1 and b"in-place" in mid.lib.mid_last_error()
     assert mid.lib.mid_bilateral_layers(ctx.handle, ctypes.byref(bp), fr[0].ptr, tbl, 1, o[0].ptr, None) == 0
     ctx.sync()
+    # the streaming passes change the pixel stride: never in place
+    zp = mid.NormalizeParams(8, 8)
+    Wb = ctx.alloc(8 * 8 * 32)
+    assert mid.lib.mid_normalize(ctx.handle, ctypes.byref(zp), Wb.ptr, Wb.ptr, None) == 1 and b"WeightInfo" in mid.lib.mid_last_error()
+    assert mid.lib.mid_pack_u8(ctx.handle, o[0].ptr, 8 * 8 * 4, o[0].ptr, None) == 1 and b"in place" in mid.lib.mid_last_error()
+    assert mid.lib.mid_unpack_u8(ctx.handle, o[0].ptr, 8 * 8 * 4, 0, o[0].ptr, None) == 1
 
 
 def test_bilateral_batch_chunks_beyond_the_frame_table(ctx):

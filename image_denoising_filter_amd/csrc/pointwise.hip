@@ -115,7 +115,7 @@ extern "C" int mid_unpack_u8(mid_ctx *ctx, const uint8_t *in, size_t n_values, i
     if (b.rc) return b.rc;
     MID_REQUIRE(in && out, "unpack_u8: NULL pointer");
     MID_REQUIRE(flavour == 0 || flavour == 1, "unpack_u8: flavour %d is not 0 (UNORM) or 1 (CPU)", flavour);
-    MID_REQUIRE((const void *)in != (const void *)out, "unpack_u8: in == out (the conversion is not in place)");
+    MID_REQUIRE(n_values == 0 || (const void *)in != (const void *)out, "unpack_u8: in == out (the conversion is not in place)");
     MID_REQUIRE(((uintptr_t)in & 3u) == 0 && ((uintptr_t)out & 15u) == 0, "unpack_u8: in must be 4-byte and out 16-byte aligned");
     const size_t npix = n_values / 4;
     if (npix) {
@@ -135,7 +135,7 @@ extern "C" int mid_pack_u8(mid_ctx *ctx, const float *in, size_t n_values, uint8
     Bind b(ctx, stream);
     if (b.rc) return b.rc;
     MID_REQUIRE(in && out, "pack_u8: NULL pointer");
-    MID_REQUIRE((const void *)in != (const void *)out, "pack_u8: in == out (the conversion is not in place)");
+    MID_REQUIRE(n_values == 0 || (const void *)in != (const void *)out, "pack_u8: in == out (the conversion is not in place)");
     MID_REQUIRE(((uintptr_t)out & 3u) == 0 && ((uintptr_t)in & 15u) == 0, "pack_u8: out must be 4-byte and in 16-byte aligned");
     const size_t npix = n_values / 4;
     if (npix) hipLaunchKernelGGL(pack_kernel, dim3(stream_grid(ctx, npix)), dim3(256), 0, b.s, (const float4 *)in, (uint32_t *)out, npix);

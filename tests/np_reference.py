@@ -73,3 +73,34 @@ def nlm_sums(target, nb, hparam, search, patch):
             num += npad[P + sy:P + sy + h, P + sx:P + sx + w] * wt[..., None]
             den += wt
     return num, den
+
+
+def nlm_step_edge_known_answer(w, xe, A, B, hparam, search, patch, neighbours=None):
+    """Closed form of shaders/nonlocal.comp for a VERTICAL STEP EDGE, derived by hand from the shader's text (no image loops, no
+    oracle, no float64 checker): every pixel left of column xe has colour A, every other pixel colour B (alpha 1).  For a target in
+    column x and the candidate at search offset (sx, sy) -- sx, sy in [search) (nonlocal.comp:36-38) -- the patch distance is a PLAIN SUM
+    over (i, j) in [patch)^2 (:42-52) of |T(p+(i,j)) - N(c+(i,j))|^2 over rgb; along the edge nothing depends on the row, so
+        d(sx) = PW * sum_{i in [patch)} |T(x+i) - N(x+sx+i)|^2_rgb,
+    the weight is exp(-d / h^2) (:55), the same for all SW values of sy, and with the 0.001 bias of the norm (:32) -- once PER NEIGHBOUR
+    FRAME, since every dispatch adds its own sums to WeightInfo (:61-62) -- and the division of normalize.comp:42
+        out(x) = sum_f sum_sx SW w_f(sx) N_f(x+sx) / sum_f (0.001 + sum_sx SW w_f(sx)).
+    neighbours: list of (A_f, B_f) step-edge frames with the same edge column (default: the target itself, the single-frame filter).
+    Returns the (w, 4) float64 row of interior rows (valid for columns at least max(|search|) + max(|patch|) away from the left / right border)."""
+    A, B = np.asarray(A, np.float64), np.asarray(B, np.float64)
+    nbs = [(A, B)] if neighbours is None else [(np.asarray(a, np.float64), np.asarray(b, np.float64)) for a, b in neighbours]
+    slo, shi = search
+    plo, phi = patch
+    PW, SW = phi - plo, shi - slo
+    col = lambda x, a, b: a if x < xe else b
+    out = np.zeros((w, 4), np.float64)
+    for x in range(w):
+        acc, norm = np.zeros(4), 0.0
+        for a, b in nbs:
+            norm += 0.001
+            for sx in range(slo, shi):
+                d = PW * sum(float(((col(x + i, A, B)[:3] - col(x + sx + i, a, b)[:3]) ** 2).sum()) for i in range(plo, phi))
+                wt = SW * np.exp(-d / (hparam * hparam))
+                acc += wt * col(x + sx, a, b)
+                norm += wt
+        out[x] = acc / norm
+    return out

@@ -183,6 +183,41 @@ def test_nlm_limits_of_the_filtering_parameter_fullsize(ctx, frame):
     assert rel_err(big[10:-10, 10:-10], box) < 2e-5
 
 
+@pytest.mark.parametrize("search,patch", [((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))])
+def test_nlm_step_edge_known_answers_fullsize(ctx, search, patch):
+    """The kernels against known answers derived by hand from nonlocal.comp's text (tests/np_reference.py::nlm_step_edge_known_answer): a
+    1920x1080 frame with a vertical step edge that is NOT on a tile seam, every interior pixel held against the closed form -- a check of the
+    headline kernel that involves neither the oracle nor the float64 checker."""
+    from np_reference import nlm_step_edge_known_answer
+    xe = 1003
+    A, B = np.float32([0.30, 0.50, 0.20, 1.0]), np.float32([0.38, 0.44, 0.26, 1.0])
+    img = np.empty((H, W, 4), np.float32)
+    img[:, :xe], img[:, xe:] = A, B
+    for hp in (0.5, 0.2):
+        want = nlm_step_edge_known_answer(W, xe, A, B, hp, search, patch)
+        got = ctx.nlm_temporal([img], k=0, hparam=hp, search=search, patch=patch)[0]
+        m = 14
+        assert rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (H - 2 * m, W - 2 * m, 4))) < 2e-5
+    # the same edge lying HORIZONTALLY, between two strips of a tile (row 517): the vertical box sums and the strip seams
+    ye = 517
+    img[:ye], img[ye:] = A, B
+    want = nlm_step_edge_known_answer(H, ye, A, B, 0.5, search, patch)
+    got = ctx.nlm_temporal([img], k=0, hparam=0.5, search=search, patch=patch)[0]
+    assert rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m, None, :], (H - 2 * m, W - 2 * m, 4))) < 2e-5
+    # three step-edge frames of different colours, the middle one filtered over all three (temporal k = 1): the per-frame 0.001 bias and
+    # the accumulation over neighbour frames (nonlocal.comp:61-62) in the fused multi-frame kernel
+    cols = [(A, B), (np.float32([0.33, 0.47, 0.22, 1.0]), np.float32([0.36, 0.46, 0.21, 1.0])),
+            (np.float32([0.27, 0.52, 0.25, 1.0]), np.float32([0.41, 0.40, 0.24, 1.0]))]
+    frames = []
+    for a, b in cols:
+        f = np.empty((H, W, 4), np.float32)
+        f[:, :xe], f[:, xe:] = a, b
+        frames.append(f)
+    want = nlm_step_edge_known_answer(W, xe, cols[1][0], cols[1][1], 0.5, search, patch, neighbours=cols)
+    got = ctx.nlm_temporal(frames, k=1, first=1, count=1, hparam=0.5, search=search, patch=patch)[0]
+    assert rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (H - 2 * m, W - 2 * m, 4))) < 2e-5
+
+
 def test_translation_equivariance_away_from_the_borders(ctx, frame):
     """Shifting the frame shifts the result: tiles, strips and wave seams land on different pixels, so this catches any
     dependence on the position inside a tile beyond rounding."""

@@ -150,6 +150,68 @@ def test_torch_float64_bilateral_checker_agrees_with_the_oracle_and_the_numpy_re
 
 
 # ---- properties ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("search,patch", [((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))])
+def test_nlm_step_edge_known_answers_derived_from_the_shader_text(search, patch):
+    """The oracle's NLM -- the checker of the headline kernel, which nothing in the reference pins -- against known answers worked out BY
+    HAND from nonlocal.comp's text for a vertical step edge (tests/np_reference.py::nlm_step_edge_known_answer): weights strictly between 0
+    and 1, the plain-sum patch distance, the half-open ranges, the 0.001 bias.  Independent of the oracle's loops and of the float64 checker."""
+    from np_reference import nlm_step_edge_known_answer
+    h, w, xe = 48, 96, 47
+    A, B = np.float32([0.30, 0.50, 0.20, 1.0]), np.float32([0.38, 0.44, 0.26, 1.0])
+    img = np.empty((h, w, 4), np.float32)
+    img[:, :xe], img[:, xe:] = A, B
+    for hp in (0.5, 0.2):
+        want = nlm_step_edge_known_answer(w, xe, A, B, hp, search, patch)
+        got = oracle.nlm_temporal([img], k=0, hparam=hp, search=search, patch=patch)[0]
+        m = 14
+        assert rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (h - 2 * m, w - 2 * m, 4))) < 1e-5      # (fp32 sums of up to 441 terms; SURVEY 8c: 2e-5)
+        # the answers are not trivial: weights across the edge are neither 0 nor 1, and the edge pixels move
+        assert 1e-3 < abs(want[xe - 1, 0] - A[0]) and abs(want[xe - 1, 0] - A[0]) < abs(B[0] - A[0])
+        # the same edge lying HORIZONTALLY (the formula is symmetric in the two axes; the loops are not)
+        got_t = oracle.nlm_temporal([np.ascontiguousarray(img.transpose(1, 0, 2))], k=0, hparam=hp, search=search, patch=patch)[0]
+        assert rel_err(got_t[m:-m, m:-m], np.broadcast_to(want[m:-m, None, :], (w - 2 * m, h - 2 * m, 4))) < 1e-5
+
+
+def test_nlm_temporal_step_edge_known_answers():
+    """Three step-edge frames of different colours, the middle one filtered over all three (k = 1): the per-frame 0.001 bias and the
+    accumulation over neighbour frames (nonlocal.comp:61-62, loop src/main.cpp:1577-1606) against the hand-derived closed form -- for the
+    oracle (fp32) and the float64 checker."""
+    import f64_checker as f64
+    from np_reference import nlm_step_edge_known_answer
+    h, w, xe, m = 48, 96, 47, 14
+    cols = [(np.float32([0.30, 0.50, 0.20, 1.0]), np.float32([0.38, 0.44, 0.26, 1.0])),
+            (np.float32([0.33, 0.47, 0.22, 1.0]), np.float32([0.36, 0.46, 0.21, 1.0])),
+            (np.float32([0.27, 0.52, 0.25, 1.0]), np.float32([0.41, 0.40, 0.24, 1.0]))]
+    frames = []
+    for a, b in cols:
+        f = np.empty((h, w, 4), np.float32)
+        f[:, :xe], f[:, xe:] = a, b
+        frames.append(f)
+    for search, patch in (((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))):
+        want = nlm_step_edge_known_answer(w, xe, cols[1][0], cols[1][1], 0.5, search, patch, neighbours=cols)
+        got = oracle.nlm_temporal(frames, k=1, hparam=0.5, search=search, patch=patch, first=1, count=1)[0]
+        assert rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (h - 2 * m, w - 2 * m, 4))) < 1e-5
+        ref = np.asarray(f64.nlm_temporal_output(frames, 1, 1, 0.5, search, patch))
+        assert np.abs(ref[m:-m, m:-m] - want[m:-m]).max() < 1e-13
+
+
+def test_float64_checker_reproduces_the_step_edge_known_answers_to_rounding():
+    """tests/f64_checker.py -- the independent float64 evaluation every whole-frame GPU test of the NLM kernels is held against -- gives the
+    hand-derived closed form to 1e-13, both edge orientations, both tuned windows: shader text -> closed form -> checker -> kernels."""
+    import f64_checker as f64
+    from np_reference import nlm_step_edge_known_answer
+    h, w, xe, m = 48, 96, 47, 14
+    A, B = np.float32([0.30, 0.50, 0.20, 1.0]), np.float32([0.38, 0.44, 0.26, 1.0])
+    img = np.empty((h, w, 4), np.float32)
+    img[:, :xe], img[:, xe:] = A, B
+    for search, patch in (((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))):
+        want = nlm_step_edge_known_answer(w, xe, A, B, 0.5, search, patch)
+        ref = np.asarray(f64.nlm_temporal_output([img], 0, 0, 0.5, search, patch))
+        assert np.abs(ref[m:-m, m:-m] - want[m:-m]).max() < 1e-13
+        ref_t = np.asarray(f64.nlm_temporal_output([np.ascontiguousarray(img.transpose(1, 0, 2))], 0, 0, 0.5, search, patch))
+        assert np.abs(ref_t[m:-m, m:-m] - want[m:-m, None, :]).max() < 1e-13
+
+
 def test_constant_image_is_invariant_in_the_interior():
     img = np.tile(np.array([0.3, 0.6, 0.9, 1.0], np.float32), (30, 34, 1))
     R = 4

@@ -1,0 +1,33 @@
+"""Observed error of the NLM kernels against the hand-derived step-edge known answers (tests/np_reference.py::nlm_step_edge_known_answer):
+every interior pixel of 1080p frames; appended to profiles/r06_parity_report.txt.  LABNOTES R6.12."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import image_denoising_filter_amd as mid
+from conftest import rel_err
+from np_reference import nlm_step_edge_known_answer
+H, W, m = 1080, 1920, 14
+ctx = mid.Context(0)
+A, B = np.float32([0.30, 0.50, 0.20, 1.0]), np.float32([0.38, 0.44, 0.26, 1.0])
+cols = [(A, B), (np.float32([0.33, 0.47, 0.22, 1.0]), np.float32([0.36, 0.46, 0.21, 1.0])), (np.float32([0.27, 0.52, 0.25, 1.0]), np.float32([0.41, 0.40, 0.24, 1.0]))]
+print("NLM kernels vs hand-derived step-edge known answers, 1920x1080, every interior pixel; max |got - want| / max(1, |want|)")
+for search, patch in (((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))):
+    xe, ye = 1003, 517
+    img = np.empty((H, W, 4), np.float32)
+    for hp in (0.5, 0.2):
+        img[:, :xe], img[:, xe:] = A, B
+        want = nlm_step_edge_known_answer(W, xe, A, B, hp, search, patch)
+        got = ctx.nlm_temporal([img], k=0, hparam=hp, search=search, patch=patch)[0]
+        print(f"  search {search} patch {patch} h={hp}: vertical edge at column {xe}: {rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (H - 2 * m, W - 2 * m, 4))):.3e}"
+              f"   (edge pixel: want {want[xe - 1, 0]:.6f}, A {A[0]:.2f}, B {B[0]:.2f})")
+    img[:ye], img[ye:] = A, B
+    want = nlm_step_edge_known_answer(H, ye, A, B, 0.5, search, patch)
+    got = ctx.nlm_temporal([img], k=0, hparam=0.5, search=search, patch=patch)[0]
+    print(f"  search {search} patch {patch} h=0.5: horizontal edge at row {ye}: {rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m, None, :], (H - 2 * m, W - 2 * m, 4))):.3e}")
+    frames = []
+    for a, b in cols:
+        f = np.empty((H, W, 4), np.float32); f[:, :xe], f[:, xe:] = a, b; frames.append(f)
+    want = nlm_step_edge_known_answer(W, xe, cols[1][0], cols[1][1], 0.5, search, patch, neighbours=cols)
+    got = ctx.nlm_temporal(frames, k=1, first=1, count=1, hparam=0.5, search=search, patch=patch)[0]
+    print(f"  search {search} patch {patch} h=0.5: temporal k=1 over three step-edge frames: {rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (H - 2 * m, W - 2 * m, 4))):.3e}")

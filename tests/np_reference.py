@@ -104,3 +104,29 @@ def nlm_step_edge_known_answer(w, xe, A, B, hparam, search, patch, neighbours=No
                 norm += wt
         out[x] = acc / norm
     return out
+
+
+def bilateral_layers_columns_known_answer(img_cols, layer_cols_u8, radius, sigma_s, sigma_c):
+    """Closed form of shaders/bialteral_layers.comp (+ normalize.comp) for frames whose colours depend on the COLUMN only, derived by hand
+    from the shader's text.  With curCoord = (x + i, y + j) (:44) the range weight -- taken on the LAYER (:45-49) -- depends on i alone and
+    the spatial weight exp(-.5 (i^2 + j^2) / sigma_s^2) (:41-42) factors into es(i) es(j); the sum over j of es(j) multiplies the weighted
+    colour sum (:53, colours from the INPUT image) and the weight sum (:54) alike, is the same for every layer, and cancels in
+    normalize.comp:42 after all layers have been accumulated (:57-58, one dispatch per layer, src/main.cpp:1610-1623):
+        out(x) = sum_L sum_i es(i) wr_L(x, i) I(x + i) / sum_L sum_i es(i) wr_L(x, i),    wr_L = exp(-.5 |L(x) - L(x+i)|^2_rgb / sigma_c^2),
+    layers UNORM-decoded (the fp32 texel c / 255, src/texture.cpp:16).  img_cols: (w, 4) colours of the image's columns; layer_cols_u8: list of (w, 4) uint8.
+    Returns (w, 4) float64, valid for columns at least `radius` away from the left / right border (and rows likewise from top / bottom)."""
+    I = np.asarray(img_cols, np.float64)
+    w = I.shape[0]
+    es = np.exp(-0.5 * (np.arange(-radius, radius + 1, dtype=np.float64) / sigma_s) ** 2)
+    num, den = np.zeros((w, 4)), np.zeros(w)
+    for lc in layer_cols_u8:
+        L = (np.asarray(lc, np.float32)[:, :3] / np.float32(255.0)).astype(np.float64)      # the texel the shader fetches: c/255 rounded to fp32
+        for x in range(radius, w - radius):
+            d2 = ((L[x] - L[x - radius:x + radius + 1]) ** 2).sum(1)
+            wt = es * np.exp(-0.5 * d2 / (sigma_c * sigma_c))
+            num[x] += wt @ I[x - radius:x + radius + 1]
+            den[x] += wt.sum()
+    out = np.zeros((w, 4))
+    ok = den > 0
+    out[ok] = num[ok] / den[ok, None]
+    return out

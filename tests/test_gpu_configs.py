@@ -66,6 +66,33 @@ def test_config3_layer_guided_bilateral_1080p_four_layers(ctx):
         assert rel_err(Wb[y0:y0 + size, x0:x0 + size, :5], Wo[R:R + size, R:R + size, :5]) < 1e-5, (y0, x0)
 
 
+def test_config3_known_answers_with_layers_that_differ_from_the_image(ctx):
+    """configs[3]'s shape (1920x1080 RGBA32F frame, four RGBA8 guide layers, r = 8) on frames whose colours depend on the column only: the
+    fused launch on every interior pixel against the closed form worked out by hand from bialteral_layers.comp's text
+    (tests/np_reference.py::bilateral_layers_columns_known_answer) -- range weight from the LAYER, colour from the IMAGE, UNORM decode, all
+    layers accumulated before the division.  Involves neither the oracle nor the float64 checker; the reference-run fixtures cover
+    layer == image only."""
+    from np_reference import bilateral_layers_columns_known_answer
+    rng = np.random.default_rng(303)
+    R = 8
+    walk = lambda lo, hi, step: np.clip(np.cumsum(rng.normal(0, step, (W, 3)), 0) + rng.uniform(lo, hi, 3), lo, hi)
+    img_cols = np.concatenate([walk(0.0, 3.0, 0.15), np.ones((W, 1))], 1).astype(np.float32)
+    layer_cols = [np.concatenate([walk(0, 255, 12.0), np.full((W, 1), 255.0)], 1).astype(np.uint8) for _ in range(4)]
+    img = np.ascontiguousarray(np.broadcast_to(img_cols, (H, W, 4)))
+    layers = [np.ascontiguousarray(np.broadcast_to(lc, (H, W, 4))) for lc in layer_cols]
+    want = bilateral_layers_columns_known_answer(img_cols, layer_cols, R, 2.0, 0.2)
+    got = ctx.bilateral_layers(img, layers, R, 2.0, 0.2)
+    err = rel_err(got[R:-R, R:-R], np.broadcast_to(want[R:-R], (H - 2 * R, W - 2 * R, 4)))
+    assert err < 1e-5, err
+    assert np.abs(want[R:-R, :3] - img_cols[R:-R, :3]).max() > 0.05          # the guide layers do move the result
+    # and the same frames transposed in memory terms: row-only colours (the vertical taps carry the range weights)
+    img_t = np.ascontiguousarray(np.broadcast_to(img_cols[:H, None, :], (H, W, 4)))
+    layers_t = [np.ascontiguousarray(np.broadcast_to(lc[:H, None, :], (H, W, 4))) for lc in layer_cols]
+    want_t = bilateral_layers_columns_known_answer(img_cols[:H], [lc[:H] for lc in layer_cols], R, 2.0, 0.2)
+    got_t = ctx.bilateral_layers(img_t, layers_t, R, 2.0, 0.2)
+    assert rel_err(got_t[R:-R, R:-R], np.broadcast_to(want_t[R:-R, None, :], (H - 2 * R, W - 2 * R, 4))) < 1e-5
+
+
 # ---- configs[4] --------------------------------------------------------------------------------------------------
 def test_config4_temporal_k2_1080p_windows(ctx):
     """k=2 at 1920x1080 on 6 frames: outputs 0 (window clipped to 0..2), 2 and 3 (full 5-frame windows) and 5 (clipped

@@ -195,6 +195,53 @@ def test_nlm_temporal_step_edge_known_answers():
         assert np.abs(ref[m:-m, m:-m] - want[m:-m]).max() < 1e-13
 
 
+def _column_frames(rng, h, w, n_layers):
+    """An image and guide layers whose colours depend on the column only: random walks, so that range weights are neither 0 nor 1."""
+    walk = lambda lo, hi, step: np.clip(np.cumsum(rng.normal(0, step, (w, 3)), 0) + rng.uniform(lo, hi, 3), lo, hi)
+    img_cols = np.concatenate([walk(0.0, 3.0, 0.15), np.ones((w, 1))], 1).astype(np.float32)
+    layer_cols = [np.concatenate([walk(0, 255, 12.0), np.full((w, 1), 255.0)], 1).astype(np.uint8) for _ in range(n_layers)]
+    img = np.ascontiguousarray(np.broadcast_to(img_cols, (h, w, 4)))
+    layers = [np.ascontiguousarray(np.broadcast_to(lc, (h, w, 4))) for lc in layer_cols]
+    return img_cols, layer_cols, img, layers
+
+
+@pytest.mark.parametrize("R", [4, 8])
+def test_layer_guided_bilateral_known_answers_with_layers_that_differ_from_the_image(R):
+    """a3 with layer != image (the reference-run fixtures only cover layer == image): the oracle's accumulate + normalize against the closed
+    form worked out by hand from bialteral_layers.comp's text for column-only frames (tests/np_reference.py): range weight from the LAYER,
+    colour from the IMAGE, UNORM decode, three layers accumulated before the division."""
+    from np_reference import bilateral_layers_columns_known_answer
+    rng = np.random.default_rng(40 + R)
+    h, w = 3 * R + 8, 120
+    img_cols, layer_cols, img, layers = _column_frames(rng, h, w, 3)
+    want = bilateral_layers_columns_known_answer(img_cols, layer_cols, R, 2.0, 0.2)
+    Wb = np.zeros((h, w, 8), np.float32)
+    for l in layers:
+        Wb = oracle.bilateral_layers_accum(img, l, Wb, R, 2.0, 0.2)
+    got = oracle.normalize(Wb)
+    assert rel_err(got[R:-R, R:-R], np.broadcast_to(want[R:-R], (h - 2 * R, w - 2 * R, 4))) < 1e-5
+    # not trivial: the result differs from the image and from a plain (image-guided) bilateral
+    assert np.abs(want[R:-R, :3] - img_cols[R:-R, :3]).max() > 0.05
+    assert rel_err(oracle.bilateral_texture(img, R, 2.0, 0.2)[R:-R, R:-R], np.broadcast_to(want[R:-R], (h - 2 * R, w - 2 * R, 4))) > 1e-3
+
+
+def test_float64_bilateral_checker_reproduces_the_layer_known_answers_to_rounding():
+    """tests/f64_checker.py's bilateral sums (what the whole-frame GPU tests of the bilateral kernels are held against), guide != image, three
+    layers accumulated: the hand-derived closed form to 1e-12."""
+    import f64_checker as f64
+    from np_reference import bilateral_layers_columns_known_answer
+    rng = np.random.default_rng(77)
+    R, h, w = 6, 30, 90
+    img_cols, layer_cols, img, layers = _column_frames(rng, h, w, 3)
+    want = bilateral_layers_columns_known_answer(img_cols, layer_cols, R, 2.0, 0.2)
+    num, den = 0, 0
+    for l in layers:
+        n_, d_ = f64.bilateral_sums(img, l.astype(np.float32) / np.float32(255.0), R, 2.0, 0.2)
+        num, den = num + n_.cpu().numpy(), den + d_.cpu().numpy()
+    got = num / den[..., None]
+    assert np.abs(got[R:-R, R:-R] - want[R:-R]).max() < 1e-12
+
+
 def test_float64_checker_reproduces_the_step_edge_known_answers_to_rounding():
     """tests/f64_checker.py -- the independent float64 evaluation every whole-frame GPU test of the NLM kernels is held against -- gives the
     hand-derived closed form to 1e-13, both edge orientations, both tuned windows: shader text -> closed form -> checker -> kernels."""

@@ -31,3 +31,17 @@ for search, patch in (((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))):
     want = nlm_step_edge_known_answer(W, xe, cols[1][0], cols[1][1], 0.5, search, patch, neighbours=cols)
     got = ctx.nlm_temporal(frames, k=1, first=1, count=1, hparam=0.5, search=search, patch=patch)[0]
     print(f"  search {search} patch {patch} h=0.5: temporal k=1 over three step-edge frames: {rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (H - 2 * m, W - 2 * m, 4))):.3e}")
+
+# ---- layer-guided bilateral, configs[3]'s shape, layers that differ from the image (tests/np_reference.py::bilateral_layers_columns_known_answer)
+from np_reference import bilateral_layers_columns_known_answer
+rng = np.random.default_rng(303)
+print("layer-guided bilateral (4 RGBA8 layers != image, fused launch) vs the hand-derived column-only known answers, 1920x1080, every interior pixel")
+for R in (8, 4, 20):
+    walk = lambda lo, hi, step: np.clip(np.cumsum(rng.normal(0, step, (W, 3)), 0) + rng.uniform(lo, hi, 3), lo, hi)
+    img_cols = np.concatenate([walk(0.0, 3.0, 0.15), np.ones((W, 1))], 1).astype(np.float32)
+    layer_cols = [np.concatenate([walk(0, 255, 12.0), np.full((W, 1), 255.0)], 1).astype(np.uint8) for _ in range(4)]
+    img = np.ascontiguousarray(np.broadcast_to(img_cols, (H, W, 4)))
+    layers = [np.ascontiguousarray(np.broadcast_to(lc, (H, W, 4))) for lc in layer_cols]
+    want = bilateral_layers_columns_known_answer(img_cols, layer_cols, R, 2.0, 0.2)
+    got = ctx.bilateral_layers(img, layers, R, 2.0, 0.2)
+    print(f"  r = {R}: {rel_err(got[R:-R, R:-R], np.broadcast_to(want[R:-R], (H - 2 * R, W - 2 * R, 4))):.3e}   (largest shift of a pixel against the image: {np.abs(want[R:-R, :3] - img_cols[R:-R, :3]).max():.3f})")

@@ -6,8 +6,11 @@ src/main.cpp:1827-1864, compiled from /root/reference by oracle/Makefile).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 Parity status: orc_cpu_bilateral is pinned bit-for-bit against _ref and tests/golden; the
-shader restatements (a1-a6) are "parity unpinned" -- the reference has no tests, fixtures or a
-runnable GPU build (see oracle.h).
+shader restatements (a1-a6) are "parity unpinned" by the reference -- it has no tests, fixtures or a
+runnable GPU build (see oracle.h).  What they are held against instead: reference-run CPU output on blue-constant
+images (a1/a2/a3/a5/a6, tests/test_reference_fixtures.py) and known answers worked out by hand from the shaders' text
+(NLM on step-edge frames, layer-guided bilateral with layers that differ from the image: tests/np_reference.py,
+tests/test_oracle.py).
 """
 import ctypes
 import os

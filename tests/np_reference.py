@@ -113,14 +113,19 @@ def bilateral_layers_columns_known_answer(img_cols, layer_cols_u8, radius, sigma
     colour sum (:53, colours from the INPUT image) and the weight sum (:54) alike, is the same for every layer, and cancels in
     normalize.comp:42 after all layers have been accumulated (:57-58, one dispatch per layer, src/main.cpp:1610-1623):
         out(x) = sum_L sum_i es(i) wr_L(x, i) I(x + i) / sum_L sum_i es(i) wr_L(x, i),    wr_L = exp(-.5 |L(x) - L(x+i)|^2_rgb / sigma_c^2),
-    layers UNORM-decoded (the fp32 texel c / 255, src/texture.cpp:16).  img_cols: (w, 4) colours of the image's columns; layer_cols_u8: list of (w, 4) uint8.
+    layers UNORM-decoded (the fp32 texel c / 255, src/texture.cpp:16).  img_cols: (w, 4) colours of the image's columns; layer_cols_u8: list of (w, 4) uint8 (or float: a guide used as it is --
+    with the image itself as the one guide this is the plain bilateral of bialteral.comp / bialteral_linear.comp away from the row ends).
     Returns (w, 4) float64, valid for columns at least `radius` away from the left / right border (and rows likewise from top / bottom)."""
     I = np.asarray(img_cols, np.float64)
     w = I.shape[0]
     es = np.exp(-0.5 * (np.arange(-radius, radius + 1, dtype=np.float64) / sigma_s) ** 2)
     num, den = np.zeros((w, 4)), np.zeros(w)
     for lc in layer_cols_u8:
-        L = (np.asarray(lc, np.float32)[:, :3] / np.float32(255.0)).astype(np.float64)      # the texel the shader fetches: c/255 rounded to fp32
+        lc = np.asarray(lc)
+        if lc.dtype == np.uint8:
+            L = (lc.astype(np.float32)[:, :3] / np.float32(255.0)).astype(np.float64)       # the texel the shader fetches: c/255 rounded to fp32
+        else:
+            L = lc.astype(np.float64)[:, :3]           # a float guide: the PLAIN bilateral (bialteral.comp:29-73) is the case guide == image
         for x in range(radius, w - radius):
             d2 = ((L[x] - L[x - radius:x + radius + 1]) ** 2).sum(1)
             wt = es * np.exp(-0.5 * d2 / (sigma_c * sigma_c))

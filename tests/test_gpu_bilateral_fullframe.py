@@ -64,3 +64,26 @@ def test_nlm_rgba8_input_every_pixel_of_1080p(ctx):
     got = ctx.nlm_temporal([u8], k=0, search=(-10, 11), patch=(-3, 4))[0]
     ref = f64.nlm_temporal_output([u8.astype(np.float32) / np.float32(255.0)], 0, 0, 0.5, (-10, 11), (-3, 4))
     assert rel_err(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("layout", ["texture", "linear"])
+@pytest.mark.parametrize("R", [8, 20])
+def test_plain_bilateral_known_answers_on_column_only_frames(ctx, layout, R):
+    """a1 / a2 against known answers worked out by hand from bialteral.comp's text (tests/np_reference.py: for frames whose colours depend on
+    the column only the 2-D window collapses to one axis; guide == image is the plain bilateral): general colours -- the reference-run
+    fixtures are blue-constant -- on every interior pixel of 1080p, both addressings, neither the oracle nor the float64 checker involved.
+    Row-only frames exercise the other axis (and, in the linear addressing, taps that stay inside their row)."""
+    from np_reference import bilateral_layers_columns_known_answer
+    rng = np.random.default_rng(500 + R)
+    walk = lambda n: np.clip(np.cumsum(rng.normal(0, 0.06, (n, 3)), 0) + rng.uniform(0.2, 1.5, 3), 0.0, 3.0)
+    cols = np.concatenate([walk(W), np.ones((W, 1))], 1).astype(np.float32)
+    img = np.ascontiguousarray(np.broadcast_to(cols, (H, W, 4)))
+    want = bilateral_layers_columns_known_answer(cols, [cols], R, 2.0, 0.2)
+    got = ctx.bilateral(img, R, 2.0, 0.2, layout)
+    assert rel_err(got[R:-R, R:-R], np.broadcast_to(want[R:-R], (H - 2 * R, W - 2 * R, 4))) < 1e-5
+    assert np.abs(want[R:-R, :3] - cols[R:-R, :3]).max() > 0.01           # the filter does something
+    rows = cols[:H]
+    img_t = np.ascontiguousarray(np.broadcast_to(rows[:, None, :], (H, W, 4)))
+    want_t = bilateral_layers_columns_known_answer(rows, [rows], R, 2.0, 0.2)
+    got_t = ctx.bilateral(img_t, R, 2.0, 0.2, layout)
+    assert rel_err(got_t[R:-R, R:-R], np.broadcast_to(want_t[R:-R, None, :], (H - 2 * R, W - 2 * R, 4))) < 1e-5

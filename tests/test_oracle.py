@@ -225,6 +225,25 @@ def test_layer_guided_bilateral_known_answers_with_layers_that_differ_from_the_i
     assert rel_err(oracle.bilateral_texture(img, R, 2.0, 0.2)[R:-R, R:-R], np.broadcast_to(want[R:-R], (h - 2 * R, w - 2 * R, 4))) > 1e-3
 
 
+@pytest.mark.parametrize("R", [4, 10])
+def test_plain_bilateral_known_answers_general_colours(R):
+    """a1 / a2 in the oracle against the hand-derived closed form with guide == image (general colours; the reference-run fixtures are
+    blue-constant): column-only and row-only frames, both addressings, interior."""
+    from np_reference import bilateral_layers_columns_known_answer
+    rng = np.random.default_rng(60 + R)
+    h, w = 3 * R + 6, 110
+    walk = lambda n: np.clip(np.cumsum(rng.normal(0, 0.06, (n, 3)), 0) + rng.uniform(0.2, 1.5, 3), 0.0, 3.0)
+    cols = np.concatenate([walk(w), np.ones((w, 1))], 1).astype(np.float32)
+    img = np.ascontiguousarray(np.broadcast_to(cols, (h, w, 4)))
+    want = bilateral_layers_columns_known_answer(cols, [cols], R, 2.0, 0.2)
+    rows = cols[:h]
+    img_t = np.ascontiguousarray(np.broadcast_to(rows[:, None, :], (h, w, 4)))
+    want_t = bilateral_layers_columns_known_answer(rows, [rows], R, 2.0, 0.2)
+    for f in (oracle.bilateral_texture, oracle.bilateral_linear):
+        assert rel_err(f(img, R, 2.0, 0.2)[R:-R, R:-R], np.broadcast_to(want[R:-R], (h - 2 * R, w - 2 * R, 4))) < 5e-6
+        assert rel_err(f(img_t, R, 2.0, 0.2)[R:-R, R:-R], np.broadcast_to(want_t[R:-R, None, :], (h - 2 * R, w - 2 * R, 4))) < 5e-6
+
+
 def test_float64_bilateral_checker_reproduces_the_layer_known_answers_to_rounding():
     """tests/f64_checker.py's bilateral sums (what the whole-frame GPU tests of the bilateral kernels are held against), guide != image, three
     layers accumulated: the hand-derived closed form to 1e-12."""

@@ -135,3 +135,34 @@ def bilateral_layers_columns_known_answer(img_cols, layer_cols_u8, radius, sigma
     ok = den > 0
     out[ok] = num[ok] / den[ok, None]
     return out
+
+
+def nlm_columns_known_answer(target_cols, hparam, search, patch, neighbour_cols=None):
+    """nlm_step_edge_known_answer for ANY column profile: frames whose colours depend on the column only.  The derivation is the same
+    (nonlocal.comp:28-63: rows are identical, so the PW rows of a patch contribute PW times the one-row distance and the SW search rows SW
+    times the same weight):
+        d_f(x, sx) = PW * sum_{i in [patch)} |T(x+i) - N_f(x+sx+i)|^2_rgb,    w = exp(-d / h^2),
+        out(x) = sum_f sum_sx SW w N_f(x+sx) / sum_f (0.001 + sum_sx SW w).
+    target_cols: (w, 4); neighbour_cols: list of (w, 4) (default: the target itself).  Returns (w, 4) float64, valid for columns at least
+    max(|search|) + max(|patch|) away from the left / right border."""
+    T = np.asarray(target_cols, np.float64)
+    nbs = [T] if neighbour_cols is None else [np.asarray(n, np.float64) for n in neighbour_cols]
+    w = T.shape[0]
+    slo, shi = search
+    plo, phi = patch
+    PW, SW = phi - plo, shi - slo
+    m = max(-slo, shi - 1) + max(-plo, phi - 1)
+    out = np.zeros((w, 4))
+    xs = np.arange(m, w - m)
+    num, den = np.zeros((len(xs), 4)), np.zeros(len(xs))
+    for N in nbs:
+        den += 0.001
+        for sx in range(slo, shi):
+            d = np.zeros(len(xs))
+            for i in range(plo, phi):
+                d += ((T[xs + i, :3] - N[xs + sx + i, :3]) ** 2).sum(1)
+            wt = SW * np.exp(-(PW * d) / (hparam * hparam))
+            num += wt[:, None] * N[xs + sx]
+            den += wt
+    out[xs] = num / den[:, None]
+    return out

@@ -218,6 +218,31 @@ def test_nlm_step_edge_known_answers_fullsize(ctx, search, patch):
     assert rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (H - 2 * m, W - 2 * m, 4))) < 2e-5
 
 
+@pytest.mark.parametrize("search,patch", [((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))])
+def test_nlm_temporal_k2_known_answers_for_general_profiles_fullsize(ctx, search, patch):
+    """configs[4]'s window (+-2 frames) at 1920x1080 on five frames with independent random-walk profiles -- column-only, then row-only -- so that
+    every weight is a generic value in (0, 1): the fused multi-frame kernel on every interior pixel against the hand-derived closed form
+    (tests/np_reference.py::nlm_columns_known_answer); the single-frame launch likewise."""
+    from np_reference import nlm_columns_known_answer
+    rng = np.random.default_rng(41)
+    m = 14
+    walk = lambda n: np.clip(np.cumsum(rng.normal(0, 0.02, (n, 3)), 0) + rng.uniform(0.2, 0.8, 3), 0, 2)
+    fr_cols = [np.concatenate([walk(W), np.ones((W, 1))], 1).astype(np.float32) for _ in range(5)]
+    frames = [np.ascontiguousarray(np.broadcast_to(c, (H, W, 4))) for c in fr_cols]
+    want = nlm_columns_known_answer(fr_cols[2], 0.5, search, patch, neighbour_cols=fr_cols)
+    got = ctx.nlm_temporal(frames, k=2, first=2, count=1, hparam=0.5, search=search, patch=patch)[0]
+    assert rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (H - 2 * m, W - 2 * m, 4))) < 2e-5
+    assert np.abs(want[m:-m, :3] - fr_cols[2][m:-m, :3]).max() > 0.02
+    want1 = nlm_columns_known_answer(fr_cols[0], 0.5, search, patch)
+    got1 = ctx.nlm_temporal([frames[0]], k=0, hparam=0.5, search=search, patch=patch)[0]
+    assert rel_err(got1[m:-m, m:-m], np.broadcast_to(want1[m:-m], (H - 2 * m, W - 2 * m, 4))) < 2e-5
+    rows = [c[:H] for c in fr_cols]
+    frames_t = [np.ascontiguousarray(np.broadcast_to(r[:, None, :], (H, W, 4))) for r in rows]
+    want_t = nlm_columns_known_answer(rows[2], 0.5, search, patch, neighbour_cols=rows)
+    got_t = ctx.nlm_temporal(frames_t, k=2, first=2, count=1, hparam=0.5, search=search, patch=patch)[0]
+    assert rel_err(got_t[m:-m, m:-m], np.broadcast_to(want_t[m:-m, None, :], (H - 2 * m, W - 2 * m, 4))) < 2e-5
+
+
 def test_translation_equivariance_away_from_the_borders(ctx, frame):
     """Shifting the frame shifts the result: tiles, strips and wave seams land on different pixels, so this catches any
     dependence on the position inside a tile beyond rounding."""

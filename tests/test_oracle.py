@@ -261,6 +261,25 @@ def test_float64_bilateral_checker_reproduces_the_layer_known_answers_to_roundin
     assert np.abs(got[R:-R, R:-R] - want[R:-R]).max() < 1e-12
 
 
+def test_nlm_temporal_k2_known_answers_for_general_column_profiles():
+    """configs[4]'s window (+-2 frames) on five frames with INDEPENDENT random-walk column profiles: every weight is a generic value in (0, 1).
+    Oracle (fp32) and float64 checker against tests/np_reference.py::nlm_columns_known_answer (the step-edge derivation for any profile)."""
+    import f64_checker as f64
+    from np_reference import nlm_columns_known_answer
+    rng = np.random.default_rng(3)
+    h, w, m = 44, 96, 14
+    walk = lambda n: np.clip(np.cumsum(rng.normal(0, 0.02, (n, 3)), 0) + rng.uniform(0.2, 0.8, 3), 0, 2)
+    fr_cols = [np.concatenate([walk(w), np.ones((w, 1))], 1).astype(np.float32) for _ in range(5)]
+    frames = [np.ascontiguousarray(np.broadcast_to(c, (h, w, 4))) for c in fr_cols]
+    for search, patch in (((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))):
+        want = nlm_columns_known_answer(fr_cols[2], 0.5, search, patch, neighbour_cols=fr_cols)
+        got = oracle.nlm_temporal(frames, k=2, hparam=0.5, search=search, patch=patch, first=2, count=1)[0]
+        assert rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (h - 2 * m, w - 2 * m, 4))) < 1e-5
+        ref = np.asarray(f64.nlm_temporal_output(frames, 2, 2, 0.5, search, patch))
+        assert np.abs(ref[m:-m, m:-m] - want[m:-m]).max() < 1e-12
+        assert np.abs(want[m:-m, :3] - fr_cols[2][m:-m, :3]).max() > 0.02
+
+
 def test_float64_checker_reproduces_the_step_edge_known_answers_to_rounding():
     """tests/f64_checker.py -- the independent float64 evaluation every whole-frame GPU test of the NLM kernels is held against -- gives the
     hand-derived closed form to 1e-13, both edge orientations, both tuned windows: shader text -> closed form -> checker -> kernels."""

@@ -45,3 +45,21 @@ for R in (8, 4, 20):
     want = bilateral_layers_columns_known_answer(img_cols, layer_cols, R, 2.0, 0.2)
     got = ctx.bilateral_layers(img, layers, R, 2.0, 0.2)
     print(f"  r = {R}: {rel_err(got[R:-R, R:-R], np.broadcast_to(want[R:-R], (H - 2 * R, W - 2 * R, 4))):.3e}   (largest shift of a pixel against the image: {np.abs(want[R:-R, :3] - img_cols[R:-R, :3]).max():.3f})")
+
+# ---- NLM, general column / row profiles, temporal k = 2 (configs[4]'s window): tests/np_reference.py::nlm_columns_known_answer
+from np_reference import nlm_columns_known_answer
+print("NLM temporal k=2 over five frames with independent random-walk profiles vs the hand-derived closed form, 1920x1080, every interior pixel")
+rng = np.random.default_rng(41)
+walk = lambda n: np.clip(np.cumsum(rng.normal(0, 0.02, (n, 3)), 0) + rng.uniform(0.2, 0.8, 3), 0, 2)
+fr_cols = [np.concatenate([walk(W), np.ones((W, 1))], 1).astype(np.float32) for _ in range(5)]
+frames = [np.ascontiguousarray(np.broadcast_to(c, (H, W, 4))) for c in fr_cols]
+rows = [c[:H] for c in fr_cols]
+frames_t = [np.ascontiguousarray(np.broadcast_to(r[:, None, :], (H, W, 4))) for r in rows]
+for search, patch in (((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))):
+    want = nlm_columns_known_answer(fr_cols[2], 0.5, search, patch, neighbour_cols=fr_cols)
+    got = ctx.nlm_temporal(frames, k=2, first=2, count=1, hparam=0.5, search=search, patch=patch)[0]
+    want_t = nlm_columns_known_answer(rows[2], 0.5, search, patch, neighbour_cols=rows)
+    got_t = ctx.nlm_temporal(frames_t, k=2, first=2, count=1, hparam=0.5, search=search, patch=patch)[0]
+    print(f"  search {search} patch {patch}: column profiles {rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (H - 2 * m, W - 2 * m, 4))):.3e}, "
+          f"row profiles {rel_err(got_t[m:-m, m:-m], np.broadcast_to(want_t[m:-m, None, :], (H - 2 * m, W - 2 * m, 4))):.3e}"
+          f"   (largest shift of a pixel: {np.abs(want[m:-m, :3] - fr_cols[2][m:-m, :3]).max():.3f})")

@@ -241,6 +241,15 @@ def test_nlm_temporal_k2_known_answers_for_general_profiles_fullsize(ctx, search
     want_t = nlm_columns_known_answer(rows[2], 0.5, search, patch, neighbour_cols=rows)
     got_t = ctx.nlm_temporal(frames_t, k=2, first=2, count=1, hparam=0.5, search=search, patch=patch)[0]
     assert rel_err(got_t[m:-m, m:-m], np.broadcast_to(want_t[m:-m, None, :], (H - 2 * m, W - 2 * m, 4))) < 2e-5
+    # RGBA8 frames (the reference's default PNG path: UNORM texels c / 255 in fp32, src/texture.cpp:16), h = 0.2 so that 8-bit steps matter
+    u8_cols = [np.concatenate([np.clip(np.cumsum(rng.normal(0, 1.5, (W, 3)), 0) + rng.uniform(60, 200, 3), 0, 255), np.full((W, 1), 255.0)], 1).astype(np.uint8)
+               for _ in range(3)]
+    frames_u8 = [np.ascontiguousarray(np.broadcast_to(c, (H, W, 4))) for c in u8_cols]
+    dec = [c.astype(np.float32) / np.float32(255.0) for c in u8_cols]
+    want8 = nlm_columns_known_answer(dec[1], 0.2, search, patch, neighbour_cols=dec)
+    got8 = ctx.nlm_temporal(frames_u8, k=1, first=1, count=1, hparam=0.2, search=search, patch=patch)[0]
+    assert rel_err(got8[m:-m, m:-m], np.broadcast_to(want8[m:-m], (H - 2 * m, W - 2 * m, 4))) < 2e-5
+    assert np.abs(want8[m:-m, :3] - dec[1][m:-m, :3]).max() > 0.005
 
 
 def test_translation_equivariance_away_from_the_borders(ctx, frame):

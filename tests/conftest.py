@@ -31,6 +31,19 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
 
 
+def additive_frames(rng, h, w, n):
+    """n frames colour(x, y) = f(x) + g(y) with f, g random walks on a 1/4096 grid, so that the sum is exact in fp32 and the float32 frame
+    the filters see IS the additive frame the known answer is worked out for."""
+    out = []
+    for _ in range(n):
+        f = np.round((np.cumsum(rng.normal(0, 0.02, (w, 3)), 0) + rng.uniform(0.2, 0.5, 3)) * 4096) / 4096
+        g = np.round((np.cumsum(rng.normal(0, 0.02, (h, 3)), 0) + rng.uniform(0.1, 0.4, 3)) * 4096) / 4096
+        img = np.concatenate([f[None, :, :] + g[:, None, :], np.ones((h, w, 1))], 2).astype(np.float32)
+        assert np.array_equal(img[..., :3].astype(np.float64), f[None] + g[:, None])
+        out.append((f, g, img))
+    return out
+
+
 def synth_ldr(rng, h, w):
     """8-bit test image: gradient + hard-edged discs + noise (scaled down)."""
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)

@@ -166,3 +166,42 @@ def nlm_columns_known_answer(target_cols, hparam, search, patch, neighbour_cols=
             den += wt
     out[xs] = num / den[:, None]
     return out
+
+
+def nlm_additive_known_answer(f, g, hparam, search, patch, neighbours=None):
+    """Known answers of shaders/nonlocal.comp for frames that vary in BOTH axes: colour(x, y) = f(x) + g(y) per channel (alpha 1).  Worked
+    out by hand: with dF_i = f(x+i) - f'(x+sx+i) and dG_j = g(y+j) - g'(y+sy+j) the patch distance (:42-52, a plain sum over the PW x PW
+    patch) is
+        d = sum_ch [ PW sum_i dF_i^2 + PW sum_j dG_j^2 + 2 (sum_i dF_i)(sum_j dG_j) ],
+    so it needs 1-D sums only; then w = exp(-d / h^2) (:55) and out = sum_f sum_s w N_f(p + s) / sum_f (0.001 + sum_s w) (:32,56-57,61-62,
+    normalize.comp:42) with N_f(x, y) = f'(x) + g'(y).  No image loops, no box filters -- unlike the oracle, the NumPy restatement and the
+    float64 checker.  f: (w, 3), g: (h, 3); neighbours: list of (f', g') (default: the frame itself).  Returns (h, w, 4) float64, NaN where
+    the window or the patch would leave the image (margin max(|search|) + max(|patch|))."""
+    f, g = np.asarray(f, np.float64), np.asarray(g, np.float64)
+    nbs = [(f, g)] if neighbours is None else [(np.asarray(a, np.float64), np.asarray(b, np.float64)) for a, b in neighbours]
+    w, h = f.shape[0], g.shape[0]
+    slo, shi = search
+    plo, phi = patch
+    PW, SW = phi - plo, shi - slo
+    m = max(-slo, shi - 1) + max(-plo, phi - 1)
+    xs, ys = np.arange(m, w - m), np.arange(m, h - m)
+    ss, pp = np.arange(slo, shi), np.arange(plo, phi)
+    num = np.zeros((len(ys), len(xs), 4))
+    den = np.zeros((len(ys), len(xs)))
+
+    def sums(t, n, pos):                                   # -> sum_i d^2 over channels [pos, s], sum_i d per channel [pos, s, ch]
+        d = t[pos[:, None, None] + pp[None, None, :]] - n[pos[:, None, None] + ss[None, :, None] + pp[None, None, :]]     # [pos, s, i, ch]
+        return (d ** 2).sum((2, 3)), d.sum(2)
+    for fn, gn in nbs:
+        A2, A1 = sums(f, fn, xs)
+        B2, B1 = sums(g, gn, ys)
+        d = PW * A2[None, :, None, :] + PW * B2[:, None, :, None] + 2.0 * np.einsum("xsc,ytc->yxts", A1, B1)               # [y, x, sy, sx]
+        wt = np.exp(-d / (hparam * hparam))
+        den += 0.001 + wt.sum((2, 3))
+        cx = fn[xs[:, None] + ss[None, :]]                 # candidate's f'(x + sx): [x, sx, ch]
+        cy = gn[ys[:, None] + ss[None, :]]                 # candidate's g'(y + sy): [y, sy, ch]
+        num[..., :3] += np.einsum("yxts,xsc->yxc", wt, cx) + np.einsum("yxts,ytc->yxc", wt, cy)
+        num[..., 3] += wt.sum((2, 3))
+    out = np.full((h, w, 4), np.nan)
+    out[m:h - m, m:w - m] = num / den[..., None]
+    return out

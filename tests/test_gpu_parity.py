@@ -546,6 +546,26 @@ def test_bilateral_batch_argument_errors(ctx):
     ctx.sync()
 
 
+@pytest.mark.parametrize("search,patch", [((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))])
+def test_nlm_known_answers_for_frames_that_vary_in_both_axes(ctx, search, patch):
+    """The NLM kernels (fused temporal k = 1, and the single-frame launch with its HALF tail) on frames colour(x, y) = f(x) + g(y) against the
+    known answers worked out by hand from the shader's text (tests/np_reference.py::nlm_additive_known_answer: 1-D sums + a cross term, no
+    image loops): 160 x 240 = 5 x 5 tiles, every pixel whose window and patch stay inside the image."""
+    from conftest import additive_frames
+    from np_reference import nlm_additive_known_answer
+    rng = np.random.default_rng(19)
+    h, w = 160, 240
+    frs = additive_frames(rng, h, w, 3)
+    m = max(-search[0], search[1] - 1) + max(-patch[0], patch[1] - 1)
+    want = nlm_additive_known_answer(frs[1][0], frs[1][1], 0.5, search, patch, neighbours=[(a, b) for a, b, _ in frs])
+    got = ctx.nlm_temporal([x[2] for x in frs], k=1, first=1, count=1, hparam=0.5, search=search, patch=patch)[0]
+    assert rel_err(got[m:-m, m:-m], want[m:-m, m:-m]) < 2e-5
+    want1 = nlm_additive_known_answer(frs[0][0], frs[0][1], 0.5, search, patch)
+    got1 = ctx.nlm_temporal([frs[0][2]], k=0, hparam=0.5, search=search, patch=patch)[0]
+    assert rel_err(got1[m:-m, m:-m], want1[m:-m, m:-m]) < 2e-5
+    assert np.abs(want1[m:-m, m:-m, :3] - frs[0][2][m:-m, m:-m, :3]).max() > 0.03
+
+
 def test_nlm_temporal_and_layers_refuse_aliased_outputs(ctx):
     """Every output frame of a launch is computed concurrently from the frames around it: an output that is a frame of the sequence (in place,
     ping-pong tables shifted by a slot) or a buffer given twice is refused before anything is launched, like mid_bilateral_batch."""

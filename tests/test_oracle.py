@@ -280,6 +280,26 @@ def test_nlm_temporal_k2_known_answers_for_general_column_profiles():
         assert np.abs(want[m:-m, :3] - fr_cols[2][m:-m, :3]).max() > 0.02
 
 
+def test_nlm_known_answers_for_frames_that_vary_in_both_axes():
+    """colour(x, y) = f(x) + g(y): the patch distance needs 1-D sums only (tests/np_reference.py::nlm_additive_known_answer, worked out by
+    hand from nonlocal.comp's text), yet both box-sum axes, every search offset and the cross term carry generic values.  Temporal k = 1 over
+    three such frames: float64 checker to 1e-13, oracle to 1e-5."""
+    import f64_checker as f64
+    from conftest import additive_frames
+    from np_reference import nlm_additive_known_answer
+    rng = np.random.default_rng(9)
+    h, w = 50, 70
+    frs = additive_frames(rng, h, w, 3)
+    for search, patch in (((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))):
+        m = max(-search[0], search[1] - 1) + max(-patch[0], patch[1] - 1)
+        want = nlm_additive_known_answer(frs[1][0], frs[1][1], 0.5, search, patch, neighbours=[(a, b) for a, b, _ in frs])
+        got = oracle.nlm_temporal([x[2] for x in frs], k=1, hparam=0.5, search=search, patch=patch, first=1, count=1)[0]
+        assert rel_err(got[m:-m, m:-m], want[m:-m, m:-m]) < 1e-5
+        ref = np.asarray(f64.nlm_temporal_output([x[2] for x in frs], 1, 1, 0.5, search, patch))
+        assert np.abs(ref[m:-m, m:-m] - want[m:-m, m:-m]).max() < 1e-13
+        assert np.abs(want[m:-m, m:-m, :3] - frs[1][2][m:-m, m:-m, :3]).max() > 0.03
+
+
 def test_float64_checker_reproduces_the_step_edge_known_answers_to_rounding():
     """tests/f64_checker.py -- the independent float64 evaluation every whole-frame GPU test of the NLM kernels is held against -- gives the
     hand-derived closed form to 1e-13, both edge orientations, both tuned windows: shader text -> closed form -> checker -> kernels."""

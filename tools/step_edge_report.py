@@ -63,3 +63,18 @@ for search, patch in (((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))):
     print(f"  search {search} patch {patch}: column profiles {rel_err(got[m:-m, m:-m], np.broadcast_to(want[m:-m], (H - 2 * m, W - 2 * m, 4))):.3e}, "
           f"row profiles {rel_err(got_t[m:-m, m:-m], np.broadcast_to(want_t[m:-m, None, :], (H - 2 * m, W - 2 * m, 4))):.3e}"
           f"   (largest shift of a pixel: {np.abs(want[m:-m, :3] - fr_cols[2][m:-m, :3]).max():.3f})")
+
+# ---- NLM on frames that vary in both axes, colour(x, y) = f(x) + g(y): tests/np_reference.py::nlm_additive_known_answer
+from conftest import additive_frames
+from np_reference import nlm_additive_known_answer
+print("NLM on additive frames f(x) + g(y), 360 x 480 (12 x 9 tiles), temporal k=1 over three frames / single frame, every pixel whose window stays inside")
+rng = np.random.default_rng(19)
+frs = additive_frames(rng, 360, 480, 3)
+for search, patch in (((-7, 7), (-3, 3)), ((-10, 11), (-3, 4))):
+    mm = max(-search[0], search[1] - 1) + max(-patch[0], patch[1] - 1)
+    want = nlm_additive_known_answer(frs[1][0], frs[1][1], 0.5, search, patch, neighbours=[(a, b) for a, b, _ in frs])
+    got = ctx.nlm_temporal([x[2] for x in frs], k=1, first=1, count=1, hparam=0.5, search=search, patch=patch)[0]
+    want1 = nlm_additive_known_answer(frs[0][0], frs[0][1], 0.5, search, patch)
+    got1 = ctx.nlm_temporal([frs[0][2]], k=0, hparam=0.5, search=search, patch=patch)[0]
+    print(f"  search {search} patch {patch}: temporal {rel_err(got[mm:-mm, mm:-mm], want[mm:-mm, mm:-mm]):.3e}, single frame {rel_err(got1[mm:-mm, mm:-mm], want1[mm:-mm, mm:-mm]):.3e}"
+          f"   (largest shift of a pixel: {np.abs(want1[mm:-mm, mm:-mm, :3] - frs[0][2][mm:-mm, mm:-mm, :3]).max():.3f})")
